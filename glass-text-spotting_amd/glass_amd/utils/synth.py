@@ -1,0 +1,196 @@
+"""Deterministic synthetic checkpoint / image / box generators.
+
+There is no network, so neither the reference's released checkpoints nor its datasets
+exist on either box.  `make_state_dict` emits a detectron2-keyed state dict with the
+exact parameter names and shapes of the reference model (the key list of SURVEY.md §8b;
+names follow reference glass/modeling/fusion/local_feature_extraction.py:103-132,
+fusion_modules.py:48-65, recognition/recognizer_encoder.py:105-127,
+recognition/prediction_aster.py:233-284, roi_heads/rotated_fast_rcnn.py:536-550 and
+detectron2 v0.6's ResNet/FPN/RPN/FastRCNNConvFCHead module names [d2-recall]).
+
+All draws come from one CPU `torch.Generator`, in a fixed order, so the same seed gives
+bit-identical tensors here and on the GPU box.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import torch
+
+
+class _Gen:
+    def __init__(self, seed: int):
+        self.g = torch.Generator(device="cpu")
+        self.g.manual_seed(seed)
+
+    def normal(self, shape, std=1.0, mean=0.0):
+        return torch.randn(shape, generator=self.g, dtype=torch.float32) * std + mean
+
+    def uniform(self, shape, lo, hi):
+        return torch.rand(shape, generator=self.g, dtype=torch.float32) * (hi - lo) + lo
+
+
+def _conv(sd, g, name, cout, cin, kh, kw, bias=False, gain=1.0):
+    fan_in = cin * kh * kw
+    sd[name + ".weight"] = g.normal((cout, cin, kh, kw), std=gain * math.sqrt(2.0 / fan_in))
+    if bias:
+        sd[name + ".bias"] = g.normal((cout,), std=0.1)
+
+
+def _bn(sd, g, name, c, gamma_scale=1.0, track=False):
+    sd[name + ".weight"] = g.uniform((c,), 0.5, 1.5) * gamma_scale
+    sd[name + ".bias"] = g.normal((c,), std=0.1)
+    sd[name + ".running_mean"] = g.normal((c,), std=0.1)
+    sd[name + ".running_var"] = g.uniform((c,), 0.5, 1.5)
+    if track:
+        sd[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+
+def _linear(sd, g, name, cout, cin, gain=1.0):
+    sd[name + ".weight"] = g.normal((cout, cin), std=gain * math.sqrt(2.0 / cin))
+    sd[name + ".bias"] = g.normal((cout,), std=0.1)
+
+
+# ResNet-50 stage table: (name, blocks, bottleneck width, out channels)
+RESNET50_STAGES = (("res2", 3, 64, 256), ("res3", 4, 128, 512), ("res4", 6, 256, 1024),
+                   ("res5", 3, 512, 2048))
+# local extractor ("Res34"-style): BasicBlock counts [1,2,5,3], widths 64/128/256/256
+LOCAL_LAYERS = ((1, 64), (2, 128), (5, 256), (3, 256))
+RES_BRANCH_GAMMA = 0.25   # last norm of every residual branch: keeps activations O(1..10)
+
+
+def make_state_dict(seed: int = 1234, num_classes: int = 1, num_chars: int = 97,
+                    num_anchors: int = 12, box_pool: int = 7, fc_dim: int = 2048,
+                    parts: Tuple[str, ...] = ("backbone", "rpn", "box", "recog")) -> "OrderedDict[str, torch.Tensor]":
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    # each part has its own stream so a test can build only what it needs and still get
+    # the same tensors as the full model
+    if "backbone" in parts:
+        g = _Gen(seed)
+        p = "backbone.bottom_up."
+        # pixel values are O(100): scale the stem so the trunk runs at O(1)
+        _conv(sd, g, p + "stem.conv1", 64, 3, 7, 7, gain=1.0 / 64)
+        _bn(sd, g, p + "stem.conv1.norm", 64)
+        cin = 64
+        for sname, nblk, width, cout in RESNET50_STAGES:
+            for b in range(nblk):
+                q = f"{p}{sname}.{b}."
+                if cin != cout:
+                    _conv(sd, g, q + "shortcut", cout, cin, 1, 1)
+                    _bn(sd, g, q + "shortcut.norm", cout)
+                _conv(sd, g, q + "conv1", width, cin, 1, 1)
+                _bn(sd, g, q + "conv1.norm", width)
+                _conv(sd, g, q + "conv2", width, width, 3, 3)
+                _bn(sd, g, q + "conv2.norm", width)
+                _conv(sd, g, q + "conv3", cout, width, 1, 1)
+                _bn(sd, g, q + "conv3.norm", cout, gamma_scale=RES_BRANCH_GAMMA)
+                cin = cout
+        for lvl, c in zip((2, 3, 4, 5), (256, 512, 1024, 2048)):
+            _conv(sd, g, f"backbone.fpn_lateral{lvl}", 256, c, 1, 1, gain=0.7)
+            _bn(sd, g, f"backbone.fpn_lateral{lvl}.norm", 256)
+            _conv(sd, g, f"backbone.fpn_output{lvl}", 256, 256, 3, 3, gain=0.7)
+            _bn(sd, g, f"backbone.fpn_output{lvl}.norm", 256)
+    if "rpn" in parts:
+        g = _Gen(seed + 1)
+        p = "proposal_generator.rpn_head."
+        _conv(sd, g, p + "conv", 256, 256, 3, 3, bias=True, gain=0.7)
+        _conv(sd, g, p + "objectness_logits", num_anchors, 256, 1, 1, bias=True)
+        _conv(sd, g, p + "anchor_deltas", num_anchors * 5, 256, 1, 1, bias=True, gain=0.15)
+    if "box" in parts:
+        g = _Gen(seed + 2)
+        _linear(sd, g, "roi_heads.box_head.fc1", fc_dim, 256 * box_pool * box_pool, gain=0.7)
+        _linear(sd, g, "roi_heads.box_head.fc2", fc_dim, fc_dim, gain=0.7)
+        _linear(sd, g, "roi_heads.box_predictor.cls_score", num_classes + 1, fc_dim)
+        _linear(sd, g, "roi_heads.box_predictor.bbox_pred", num_classes * 5, fc_dim, gain=0.5)
+        _linear(sd, g, "roi_heads.box_predictor.orientation_pred", 4, fc_dim)
+    if "recog" in parts:
+        g = _Gen(seed + 3)
+        _conv(sd, g, "roi_heads.recognizer_feature_fusion.conv1", 256, 256, 1, 1, gain=0.7)
+        _conv(sd, g, "roi_heads.recognizer_feature_fusion.conv2", 256, 256, 1, 1, gain=0.7)
+        p = "roi_heads.hybrid_net.ConvNet."
+        _conv(sd, g, p + "conv0_1", 16, 3, 3, 3, gain=1.0 / 64)
+        _bn(sd, g, p + "bn0_1", 16, track=True)
+        _conv(sd, g, p + "conv0_2", 32, 16, 3, 3)
+        _bn(sd, g, p + "bn0_2", 32, track=True)
+        cin = 32
+        for li, (nblk, planes) in enumerate(LOCAL_LAYERS, start=1):
+            for b in range(nblk):
+                q = f"{p}layer{li}.{b}."
+                _conv(sd, g, q + "conv1", planes, cin, 3, 3)
+                _bn(sd, g, q + "bn1", planes, track=True)
+                _conv(sd, g, q + "conv2", planes, planes, 3, 3)
+                _bn(sd, g, q + "bn2", planes, gamma_scale=RES_BRANCH_GAMMA, track=True)
+                if cin != planes:
+                    _conv(sd, g, q + "downsample.0", planes, cin, 1, 1)
+                    _bn(sd, g, q + "downsample.1", planes, track=True)
+                cin = planes
+            if li < 4:
+                _conv(sd, g, f"{p}conv{li}", planes, planes, 3, 3, gain=0.7)
+                _bn(sd, g, f"{p}bn{li}", planes, track=True)
+        _conv(sd, g, p + "conv4_1", 256, 256, 2, 2, gain=0.7)
+        _bn(sd, g, p + "bn4_1", 256, track=True)
+        p = "roi_heads.fusion_net."
+        _conv(sd, g, p + "conv_mask", 1, 64, 1, 1, bias=True)
+        _conv(sd, g, p + "channel_add_conv.0", 256, 512, 1, 1, bias=True)
+        sd[p + "channel_add_conv.1.weight"] = g.uniform((256, 1, 1), 0.5, 1.5)
+        sd[p + "channel_add_conv.1.bias"] = g.normal((256, 1, 1), std=0.1)
+        _conv(sd, g, p + "channel_add_conv.3", 512, 256, 1, 1, bias=True)
+        _conv(sd, g, p + "out", 256, 512, 3, 3, bias=True, gain=0.7)
+        p = "roi_heads.recognizer_head.backbone."
+        _conv(sd, g, p + "conv1", 256, 256, 2, 1, gain=0.7)
+        _bn(sd, g, p + "conv1.norm", 256)
+        _conv(sd, g, p + "conv2", 256, 256, 3, 3, gain=0.7)
+        _bn(sd, g, p + "conv2.norm", 256)
+        for layer in range(2):
+            q = f"roi_heads.recognizer_head.encoder.bilsm_stack.{layer}."
+            for sfx in ("", "_reverse"):
+                sd[q + f"rnn.weight_ih_l0{sfx}"] = g.normal((1024, 256), std=1.0 / 16)
+                sd[q + f"rnn.weight_hh_l0{sfx}"] = g.normal((1024, 256), std=1.0 / 16)
+                sd[q + f"rnn.bias_ih_l0{sfx}"] = g.normal((1024,), std=0.3)
+                sd[q + f"rnn.bias_hh_l0{sfx}"] = g.normal((1024,), std=0.3)
+            sd[q + "linear.weight"] = g.normal((256, 512), std=1.0 / 16)
+            sd[q + "linear.bias"] = g.normal((256,), std=0.1)
+        q = "roi_heads.recognizer_head.decoder.recognizer.decoder."
+        for nm in ("sEmbed", "xEmbed"):
+            sd[q + f"attention_unit.{nm}.weight"] = g.normal((256, 256), std=1.0 / 16)
+            sd[q + f"attention_unit.{nm}.bias"] = g.normal((256,), std=0.1)
+        sd[q + "attention_unit.wEmbed.weight"] = g.normal((1, 256), std=0.25)
+        sd[q + "attention_unit.wEmbed.bias"] = g.normal((1,), std=0.1)
+        sd[q + "tgt_embedding.weight"] = g.normal((num_chars, 256), std=1.0)
+        sd[q + "gru.weight_ih_l0"] = g.normal((768, 512), std=1.0 / 16)
+        sd[q + "gru.weight_hh_l0"] = g.normal((768, 256), std=1.0 / 16)
+        sd[q + "gru.bias_ih_l0"] = g.normal((768,), std=0.1)
+        sd[q + "gru.bias_hh_l0"] = g.normal((768,), std=0.1)
+        sd[q + "fc.weight"] = g.normal((num_chars, 256), std=0.5)
+        sd[q + "fc.bias"] = g.normal((num_chars,), std=0.1)
+        sd[q + "temperature"] = torch.ones(1)
+    return sd
+
+
+def make_image(index: int, height: int, width: int) -> torch.Tensor:
+    """uint8 HWC BGR image: U{0..255} noise smoothed by a 5x5 box filter (image seed =
+    1000 + global image index)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1000 + index)
+    x = torch.randint(0, 256, (1, 3, height + 4, width + 4), generator=g, dtype=torch.int32).float()
+    x = torch.nn.functional.avg_pool2d(x, 5, stride=1)
+    # widen the contrast the box filter removed, keep 0..255
+    x = ((x - 127.5) * 3.0 + 127.5).clamp_(0, 255)
+    return x[0].permute(1, 2, 0).round().to(torch.uint8).contiguous()
+
+
+def make_boxes(index: int, count: int, height: int, width: int) -> torch.Tensor:
+    """`count` rotated word boxes (cx,cy,w,h,angle_deg) (box seed = 2000 + index):
+    w~U(40,300), h~U(16,64), angle ~ 70% N(0,10deg) / 30% U(-180,180)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2000 + index)
+    u = torch.rand((count, 6), generator=g)
+    n = torch.randn((count,), generator=g)
+    cx = (0.1 + 0.8 * u[:, 0]) * width
+    cy = (0.1 + 0.8 * u[:, 1]) * height
+    w = 40 + 260 * u[:, 2]
+    h = 16 + 48 * u[:, 3]
+    ang = torch.where(u[:, 4] < 0.7, n * 10.0, u[:, 5] * 360.0 - 180.0)
+    return torch.stack([cx, cy, w, h, ang], dim=1).float()

@@ -1,0 +1,63 @@
+"""CPU: pin the oracle restatement (oracle/glass_cpu.py) against the golden vectors produced
+by the reference's own modules (oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from glass_amd.utils.synth import make_state_dict
+from oracle import glass_cpu as O
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return make_state_dict(1234, parts=("recog",))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_local_extractor(sd, golden_dir):
+    g = _load(golden_dir, "local_extractor.npz")
+    y = O.local_extractor(sd, torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=2e-5)
+
+
+def test_fusion_attention(sd, golden_dir):
+    g = _load(golden_dir, "fusion_attention.npz")
+    y = O.gc_attention_fusion(sd, torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=2e-5)
+
+
+def test_p2p3(sd, golden_dir):
+    g = _load(golden_dir, "p2p3_fusion.npz")
+    y = O.p2p3_fusion(sd, torch.from_numpy(g["p2"]), torch.from_numpy(g["p3"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-5)
+
+
+def test_bilstm(sd, golden_dir):
+    g = _load(golden_dir, "bilstm_encoder.npz")
+    y = O.bilstm_encoder(sd, torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-5)
+
+
+def test_decoder_and_early_break(sd, golden_dir):
+    g = _load(golden_dir, "attention_decoder.npz")
+    x = torch.from_numpy(g["x"])
+    y = O.attention_decoder(sd, x)
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=1e-5)
+    k = "roi_heads.recognizer_head.decoder.recognizer.decoder.fc.bias"
+    sd2 = dict(sd)
+    sd2[k] = sd[k].clone()
+    sd2[k][0] += float(g["bias0_break0"])
+    y2 = O.attention_decoder(sd2, x)
+    np.testing.assert_allclose(y2.numpy(), g["y_break0"], rtol=0, atol=1e-5)
+    assert (y2[:, 1:] == 0).all()
+    sd3 = dict(sd)
+    sd3[k] = sd[k].clone()
+    sd3[k][0] += float(g["bias0_partial"])
+    y3 = O.attention_decoder(sd3, torch.from_numpy(g["x_partial"]))
+    np.testing.assert_allclose(y3.numpy(), g["y_partial"], rtol=0, atol=1e-5)
+    assert (y3[:, 9:] == 0).all() and (y3[:, 8].sum(-1) > 0).all()
