@@ -1,0 +1,18 @@
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void glass_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* glass_last_error(void) { return g_err; }
+extern "C" int glass_abi_version(void) { return 1; }
+extern "C" int glass_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}

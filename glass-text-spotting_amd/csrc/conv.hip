@@ -1,0 +1,257 @@
+// Implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view:  Y[m][co] = sum_k A[m][k] * Wt[co][k],  m = (n,ho,wo) output pixel,
+// k = (kh,kw,ci) with ci fastest, so a 32-wide k-tile of A is (for Cin >= 32) 128 contiguous
+// bytes of ONE input pixel -> 16-byte coalesced NHWC loads, and Wt rows are K-contiguous.
+//
+// Block = 256 threads = 4 waves (64 lanes each).  Each wave owns TM x TN tiles of 32x32
+// accumulators (f32x16 each, in the unified VGPR/AGPR file).  Both operand tiles are staged
+// through LDS as [row][BK+4] floats: the +4 pad makes the 16-byte fragment reads
+// (ds_read_b128: lane l reads row l&31, k = 4*(l>>5)..+3) conflict-free (row stride 144 B ->
+// 16-B slot index 9*row mod 16 is a bijection over each 16-lane service group).
+// One ds_read_b128 per operand feeds 4 MFMA k-steps: step s uses k = 8g+s on lanes 0-31 and
+// k = 8g+4+s on lanes 32-63 for A and B alike, so the k-permutation cancels in the sum.
+//
+// Global->LDS staging goes through registers: the loads of k-tile t+1 are issued before the
+// MFMAs of tile t and written to LDS after them, so HBM/L2 latency hides under 64 MFMAs
+// (4096 cycles) per wave per tile.
+//
+// blockIdx -> tile map is XCD-aware: hardware places block b on XCD b%8 (each XCD has its
+// own 4 MiB L2), so each XCD gets a contiguous run of tiles whose neighbours share A rows.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* res;
+  float* y;
+  int N, H, W, Cin, Cout, KH, KW, sh, sw, ph, pw, Ho, Wo;
+  int ldx, ldy, ycoff, ycs, relu, res_mode, ldr;
+  int M, Ktot, nk, tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+  // component-wise: a whole-float4 ?: is lowered through scratch memory by hipcc
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p) {
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int A_LOADS = BM / 32;
+  constexpr int B_LOADS = BN / 32;
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+  float* As = smem;
+  float* Bs = smem + BM * LDS_LD;
+
+  // bijective XCD swizzle: XCD (bid % 8) owns a contiguous chunk of logical tile ids
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tile_m = logical / p.tiles_n;
+  const int tile_n = logical - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int cc = tid & 7;    // 16-byte chunk column inside the k-tile
+  const int r0 = tid >> 3;   // first staged row of this thread (0..31)
+
+  long a_base[A_LOADS];
+  int a_hi0[A_LOADS], a_wi0[A_LOADS];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    if (m < p.M) {
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      a_hi0[i] = ho * p.sh - p.ph;
+      a_wi0[i] = wo * p.sw - p.pw;
+      a_base[i] = ((long)n * p.H * p.W + (long)a_hi0[i] * p.W + a_wi0[i]) * p.ldx;
+    } else {
+      a_hi0[i] = -(1 << 24);
+      a_wi0[i] = 0;
+      a_base[i] = 0;
+    }
+  }
+  long b_off[B_LOADS];
+  bool b_ok[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int co = n0 + r0 + 32 * i;
+    b_ok[i] = co < p.Cout;
+    b_off[i] = (long)(b_ok[i] ? co : 0) * p.Ktot + cc * 4;
+  }
+
+  float4 areg[A_LOADS], breg[B_LOADS];
+
+  auto load_tile = [&](int kt) {
+    const int kpos = kt * BK + cc * 4;
+    const bool kvalid = kpos < p.Ktot;
+    const int tap = kpos / p.Cin;
+    const int c = kpos - tap * p.Cin;
+    const int dh = tap / p.KW;
+    const int dw = tap - dh * p.KW;
+    const long koff = ((long)dh * p.W + dw) * p.ldx + c;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
+      const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      // select the ADDRESS (not the load) so the load stays unconditional and pipelined
+      const float* src = ok ? (p.x + a_base[i] + koff) : p.x;
+      float4 v = *reinterpret_cast<const float4*>(src);
+      areg[i] = sel4(ok, v);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const bool ok = kvalid && b_ok[i];
+      const float* src = ok ? (p.w + b_off[i] + (long)kt * BK) : p.w;
+      float4 v = *reinterpret_cast<const float4*>(src);
+      breg[i] = sel4(ok, v);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i)
+      *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + cc * 4]) = areg[i];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + cc * 4]) = breg[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+  const float* a_frag = As + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
+  const float* b_frag = Bs + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const bool more = kt + 1 < p.nk;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_frag + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_frag + j * 32 * LDS_LD + g * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float a = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float b = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const int HoWo2 = (p.Ho >> 1) * (p.Wo >> 1);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool cok = co < p.Cout;
+    const float bv = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int m = m0 + (wm * TM + i) * 32 + row;
+        if (cok && m < p.M) {
+          float v = acc[i][j][e] + bv;
+          if (p.relu == 2) v = fmaxf(v, 0.f);
+          if (p.res_mode == 1) {
+            v += p.res[(long)m * p.ldr + co];
+          } else if (p.res_mode == 2) {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            v += p.res[((long)n * HoWo2 + (long)(ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * p.ldr + co];
+          }
+          if (p.relu == 1) v = fmaxf(v, 0.f);
+          p.y[(long)m * p.ldy + p.ycoff + (long)co * p.ycs] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+static int launch_conv(ConvParams& p, hipStream_t stream) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.Cout, BN);
+  const long nblk = (long)p.tiles_m * p.tiles_n;
+  if (nblk <= 0 || nblk > 0x7fffffffL) {
+    glass_set_error("glass_conv2d_nhwc: bad grid %ld", nblk);
+    return GLASS_EINVAL;
+  }
+  hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  GLASS_CHECK_LAUNCH("glass_conv2d_nhwc");
+  return GLASS_OK;
+}
+
+extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
+                                 const float* residual, float* y, glass_stream_t stream) {
+  GLASS_CHECK_ARG(d && x && w && y, "glass_conv2d_nhwc: null pointer");
+  GLASS_CHECK_ARG(d->Cin > 0 && d->Cin % 4 == 0, "glass_conv2d_nhwc: Cin=%d must be a positive multiple of 4", d->Cin);
+  GLASS_CHECK_ARG(d->ldx % 4 == 0 && d->ldx >= d->Cin, "glass_conv2d_nhwc: ldx=%d", d->ldx);
+  GLASS_CHECK_ARG(d->N >= 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0, "glass_conv2d_nhwc: bad dims");
+  GLASS_CHECK_ARG(d->stride_h > 0 && d->stride_w > 0, "glass_conv2d_nhwc: bad stride");
+  GLASS_CHECK_ARG(d->Ho == (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1 &&
+                      d->Wo == (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1,
+                  "glass_conv2d_nhwc: Ho/Wo (%d,%d) inconsistent with input/kernel/stride/pad", d->Ho, d->Wo);
+  GLASS_CHECK_ARG(d->y_cstride >= 1 && d->ldy >= 1, "glass_conv2d_nhwc: bad output strides");
+  GLASS_CHECK_ARG(d->res_mode == 0 || residual != nullptr, "glass_conv2d_nhwc: res_mode set but residual is null");
+  GLASS_CHECK_ARG(d->res_mode != 2 || (d->Ho % 2 == 0 && d->Wo % 2 == 0), "glass_conv2d_nhwc: upsampled residual needs even Ho/Wo");
+  GLASS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "glass_conv2d_nhwc: x/w must be 16-byte aligned");
+  if (d->N == 0) return GLASS_OK;
+  ConvParams p;
+  p.x = x; p.w = w; p.bias = bias; p.res = residual; p.y = y;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.ldx = d->ldx; p.ldy = d->ldy; p.ycoff = d->y_coff; p.ycs = d->y_cstride; p.relu = d->relu;
+  p.res_mode = d->res_mode; p.ldr = d->ldr;
+  const long M = (long)d->N * d->Ho * d->Wo;
+  GLASS_CHECK_ARG(M < 0x7fffffffL, "glass_conv2d_nhwc: too many output pixels");
+  p.M = (int)M;
+  p.Ktot = d->KH * d->KW * d->Cin;
+  p.nk = cdiv(p.Ktot, BK);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->Cout <= 32) return launch_conv<4, 1, 2, 1>(p, s);   // 256 x 32
+  if (d->Cout <= 64) return launch_conv<4, 1, 2, 2>(p, s);   // 256 x 64
+  if (p.M <= 64) return launch_conv<1, 4, 2, 1>(p, s);       // 64 x 128 (few rows: linear layers)
+  return launch_conv<2, 2, 2, 2>(p, s);                      // 128 x 128
+}

@@ -1,0 +1,149 @@
+// HBM-bound NHWC helpers: max pooling, image preprocess, u8->f32 resize, mean over H.
+// All are one-pass streaming kernels with 16-byte (float4) channel-vector accesses where the
+// channel count allows; grids are capped and grid-strided.
+#include "common.h"
+
+static inline int grid_for(long n, int block) {
+  long g = (n + block - 1) / block;
+  if (g > 256L * 16) g = 256L * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- max pool (C % 4 == 0)
+__global__ void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4, int KH,
+                                    int KW, int sh, int sw, int ph, int pw, int Ho, int Wo) {
+  const long total = (long)N * Ho * Wo * C4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    long t = idx / C4;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int kh = 0; kh < KH; ++kh) {
+      const int hi = ho * sh - ph + kh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int wi = wo * sw - pw + kw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const float4 v = reinterpret_cast<const float4*>(x)[((long)(n * H + hi) * W + wi) * C4 + c4];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    reinterpret_cast<float4*>(y)[idx] = m;
+  }
+}
+
+extern "C" int glass_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,
+                                    int ph, int pw, int Ho, int Wo, glass_stream_t stream) {
+  GLASS_CHECK_ARG(x && y, "glass_maxpool2d_nhwc: null pointer");
+  GLASS_CHECK_ARG(C % 4 == 0 && C > 0, "glass_maxpool2d_nhwc: C=%d must be a multiple of 4", C);
+  GLASS_CHECK_ARG(Ho == (H + 2 * ph - KH) / sh + 1 && Wo == (W + 2 * pw - KW) / sw + 1, "glass_maxpool2d_nhwc: bad Ho/Wo");
+  if (N == 0) return GLASS_OK;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W,
+                     C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo);
+  GLASS_CHECK_LAUNCH("glass_maxpool2d_nhwc");
+  return GLASS_OK;
+}
+
+// ---------------------------------------------------------------- preprocess
+__global__ void preprocess_kernel(const float* __restrict__ chw, int H, int W, float m0, float m1, float m2, float s0,
+                                  float s1, float s2, float4* __restrict__ out, int Hp, int Wp) {
+  const long total = (long)Hp * Wp;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(idx % Wp), h = (int)(idx / Wp);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (h < H && w < W) {
+      const long o = (long)h * W + w, plane = (long)H * W;
+      v.x = (chw[o] - m0) / s0;
+      v.y = (chw[plane + o] - m1) / s1;
+      v.z = (chw[2 * plane + o] - m2) / s2;
+    }
+    out[idx] = v;
+  }
+}
+
+extern "C" int glass_preprocess_image(const float* chw, int H, int W, const float* mean3, const float* std3,
+                                      float* batch_nhwc4, int n, int Hp, int Wp, glass_stream_t stream) {
+  GLASS_CHECK_ARG(chw && mean3 && std3 && batch_nhwc4, "glass_preprocess_image: null pointer");
+  GLASS_CHECK_ARG(H > 0 && W > 0 && H <= Hp && W <= Wp && n >= 0, "glass_preprocess_image: bad dims");
+  float4* out = reinterpret_cast<float4*>(batch_nhwc4) + (long)n * Hp * Wp;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((long)Hp * Wp, 256)), dim3(256), 0, (hipStream_t)stream, chw, H, W,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out, Hp, Wp);
+  GLASS_CHECK_LAUNCH("glass_preprocess_image");
+  return GLASS_OK;
+}
+
+// ---------------------------------------------------------------- u8 HWC -> f32 CHW (+ bilinear)
+// F.interpolate(mode='bilinear', align_corners=False) source index rule:
+// src = max(0, (dst + 0.5) * (in/out) - 0.5); i1 = min(i0 + 1, in - 1).
+__global__ void u8_to_chw_resize_kernel(const uint8_t* __restrict__ hwc, int H, int W, float* __restrict__ chw, int Ho,
+                                        int Wo, int flip) {
+  const long total = (long)Ho * Wo;
+  const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int wo = (int)(idx % Wo), ho = (int)(idx / Wo);
+    float v[3];
+    if (Ho == H && Wo == W) {
+      const uint8_t* p = hwc + ((long)ho * W + wo) * 3;
+      v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+    } else {
+      float fy = ((float)ho + 0.5f) * sy - 0.5f;
+      float fx = ((float)wo + 0.5f) * sx - 0.5f;
+      fy = fy < 0.f ? 0.f : fy;
+      fx = fx < 0.f ? 0.f : fx;
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+      const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+      const uint8_t* p00 = hwc + ((long)y0 * W + x0) * 3;
+      const uint8_t* p01 = hwc + ((long)y0 * W + x1) * 3;
+      const uint8_t* p10 = hwc + ((long)y1 * W + x0) * 3;
+      const uint8_t* p11 = hwc + ((long)y1 * W + x1) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        v[c] = hy * (hx * (float)p00[c] + lx * (float)p01[c]) + ly * (hx * (float)p10[c] + lx * (float)p11[c]);
+    }
+    const long plane = (long)Ho * Wo;
+    chw[idx] = v[flip ? 2 : 0];
+    chw[plane + idx] = v[1];
+    chw[2 * plane + idx] = v[flip ? 0 : 2];
+  }
+}
+
+extern "C" int glass_image_u8hwc_to_chw_resized(const uint8_t* hwc, int H, int W, float* chw, int Ho, int Wo,
+                                                int flip_channels, glass_stream_t stream) {
+  GLASS_CHECK_ARG(hwc && chw && H > 0 && W > 0 && Ho > 0 && Wo > 0, "glass_image_u8hwc_to_chw_resized: bad args");
+  hipLaunchKernelGGL(u8_to_chw_resize_kernel, dim3(grid_for((long)Ho * Wo, 256)), dim3(256), 0, (hipStream_t)stream, hwc, H,
+                     W, chw, Ho, Wo, flip_channels);
+  GLASS_CHECK_LAUNCH("glass_image_u8hwc_to_chw_resized");
+  return GLASS_OK;
+}
+
+// ---------------------------------------------------------------- mean over H
+__global__ void mean_h_kernel(const float4* __restrict__ x, float4* __restrict__ y, int R, int H, int WC4) {
+  const long total = (long)R * WC4;
+  const float fh = (float)H;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % WC4);
+    const long r = idx / WC4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < H; ++h) {
+      const float4 v = x[(r * H + h) * WC4 + j];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    y[idx] = make_float4(s.x / fh, s.y / fh, s.z / fh, s.w / fh);
+  }
+}
+
+extern "C" int glass_mean_over_h(const float* x, float* y, int R, int H, int W, int C, glass_stream_t stream) {
+  GLASS_CHECK_ARG(x && y && C % 4 == 0 && H > 0, "glass_mean_over_h: bad args");
+  if (R == 0) return GLASS_OK;
+  const int WC4 = W * C / 4;
+  hipLaunchKernelGGL(mean_h_kernel, dim3(grid_for((long)R * WC4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), R, H, WC4);
+  GLASS_CHECK_LAUNCH("glass_mean_over_h");
+  return GLASS_OK;
+}

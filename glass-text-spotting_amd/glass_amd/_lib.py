@@ -1,0 +1,92 @@
+"""Loader / builder of libglass_hip.so (the C-ABI kernel library, include/glass_hip.h).
+
+The product path has NO CPU fallback: `lib()` raises if the shared object is missing or
+does not export every declared symbol, and every op wrapper raises if its tensors are not
+on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes
+import glob
+import os
+import subprocess
+from typing import List, Optional
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)                     # glass-text-spotting_amd/
+CSRC = os.path.join(_ROOT, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_ROOT), "include")
+SO_PATH = os.path.join(_ROOT, "libglass_hip.so")
+
+EXPORTS = [
+    "glass_last_error", "glass_abi_version", "glass_device_count", "glass_conv2d_nhwc", "glass_maxpool2d_nhwc",
+    "glass_preprocess_image", "glass_image_u8hwc_to_chw_resized", "glass_roi_align_rotated",
+    "glass_rpn_topk_workspace", "glass_rpn_level_topk_decode", "glass_nms_workspace", "glass_rotated_nms_select",
+    "glass_box_decode", "glass_gc_attention_inplace", "glass_mean_over_h", "glass_bilstm_recurrence",
+    "glass_attention_decode",
+]
+
+
+class GlassLibraryError(RuntimeError):
+    pass
+
+
+def sources() -> List[str]:
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every csrc/*.hip into libglass_hip.so (in-tree)."""
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    objdir = os.path.join(_ROOT, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if (not force and os.path.exists(o) and
+                all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):])):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise GlassLibraryError(f"hipcc failed on {s}:\n{out.decode(errors='replace')}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_PATH] + objs
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_LIB: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise GlassLibraryError(
+                f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(SO_PATH)
+        missing = [s for s in EXPORTS if not hasattr(L, s)]
+        if missing:
+            raise GlassLibraryError(f"{SO_PATH} lacks symbols {missing}")
+        L.glass_last_error.restype = ctypes.c_char_p
+        L.glass_rpn_topk_workspace.restype = ctypes.c_int64
+        L.glass_nms_workspace.restype = ctypes.c_int64
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().glass_last_error().decode(errors="replace")
+        raise GlassLibraryError(f"{what or 'glass call'} failed ({rc}): {msg}")

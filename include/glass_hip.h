@@ -1,0 +1,181 @@
+/*
+ * glass_hip.h — C ABI of libglass_hip.so, the MI355X (gfx950) kernel library behind the
+ * GLASS inference hot path.
+ *
+ * The reference (amazon-science/glass-text-spotting) has no FFI of its own: its hot path
+ * reaches native code through PyTorch / detectron2==0.6 operators.  Each entry point below
+ * names the reference call site (file:line relative to the reference root) whose native
+ * work it replaces.  INTEGRATION.md shows the ctypes binding a reference maintainer adds.
+ *
+ * Conventions
+ *  - plain C, no torch types: device pointers are raw `float*`/`int*` (e.g. from
+ *    `torch.Tensor.data_ptr()`), sizes are ints, `stream` is a `hipStream_t` cast to void*.
+ *  - activations are fp32 NHWC; a "pixel stride" (ld*) is the distance in floats between
+ *    consecutive pixels, so a tensor may be a channel slice of a wider one.
+ *  - every function returns 0 on success, a negative GLASS_E* code on failure;
+ *    glass_last_error() returns a thread-local message.  Nothing throws across the ABI.
+ *  - all work is enqueued on the caller's stream; no function synchronises unless stated.
+ */
+#ifndef GLASS_HIP_H
+#define GLASS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLASS_OK 0
+#define GLASS_EINVAL (-1)   /* bad argument */
+#define GLASS_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+#define GLASS_ENOMEM (-3)   /* workspace too small */
+
+typedef void* glass_stream_t;
+
+const char* glass_last_error(void);
+int glass_abi_version(void);
+/* number of visible HIP devices (0 if none / runtime unusable) */
+int glass_device_count(void);
+
+/* ------------------------------------------------------------------ dense contraction
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC, with the
+ * epilogue y = act(conv(x,w) + bias [+ residual]).
+ * Replaces the cuDNN/MKL-DNN conv + BatchNorm(eval, folded into w/bias at load) + ReLU +
+ * residual-add sequences of: d2 ResNet/FPN/RPN head (glass/modeling/meta_arch/
+ * glass_rcnn.py:83,87), P2P3Fusion (glass/modeling/fusion/fusion_modules.py:281-286),
+ * the local extractor (glass/modeling/fusion/local_feature_extraction.py:153-188,308-323),
+ * the fusion out-conv (fusion_modules.py:156), CNN_V1_1 (glass/modeling/recognition/
+ * recognizer_backbone.py:77-81), and every nn.Linear on the path (H=W=KH=KW=1).
+ * w layout: [Cout][KH][KW][Cin] (K-contiguous per output channel), Cin % 4 == 0.       */
+typedef struct glass_conv_desc {
+  int N, H, W, Cin;              /* input: N images of H x W pixels, Cin channels used */
+  int Cout, KH, KW;
+  int stride_h, stride_w, pad_h, pad_w;
+  int Ho, Wo;                    /* output spatial size */
+  int ldx;                       /* input pixel stride (floats), >= Cin */
+  int ldy, y_coff, y_cstride;    /* output pixel stride, first channel, channel step */
+  int relu;                      /* 0 none, 1 ReLU after everything, 2 ReLU before the residual add */
+  int res_mode;                  /* 0 none, 1 same-shape residual, 2 nearest-x2-upsampled residual
+                                    (residual tensor is [N, Ho/2, Wo/2, *]) */
+  int ldr;                       /* residual pixel stride */
+} glass_conv_desc;
+
+int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
+                      const float* residual, float* y, glass_stream_t stream);
+
+/* max pooling NHWC (d2 stem max_pool2d k3 s2 p1; local extractor maxpool1..3,
+ * glass/modeling/fusion/local_feature_extraction.py:112,118,124). Padding acts as -inf. */
+int glass_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,
+                         int ph, int pw, int Ho, int Wo, glass_stream_t stream);
+
+/* ------------------------------------------------------------------ image preprocess
+ * (x - mean) / std per channel, CHW float [3,H,W] -> NHWC4 slot `n` of a zero-padded
+ * batch [N,Hp,Wp,4] (4th channel 0).  d2 GeneralizedRCNN.preprocess_image +
+ * ImageList.from_tensors at glass/modeling/meta_arch/glass_rcnn.py:82.                   */
+int glass_preprocess_image(const float* chw, int H, int W, const float* mean3, const float* std3, float* batch_nhwc4,
+                           int n, int Hp, int Wp, glass_stream_t stream);
+/* uint8 HWC (3 channels) -> float CHW with optional bilinear resize (align_corners=False):
+ * GlassRunner._image_to_tensor, glass/inference/glass_runner.py:123-148.                 */
+int glass_image_u8hwc_to_chw_resized(const uint8_t* hwc, int H, int W, float* chw, int Ho, int Wo, int flip_channels,
+                                     glass_stream_t stream);
+
+/* ------------------------------------------------------------------ rotated RoIAlign
+ * detectron2 ROIPooler(ROIAlignRotated) over up to 5 pyramid levels
+ * (glass/modeling/fusion/recognizers_hybrid_head.py:320 box pooler 7x7 sr2 p2..p6;
+ *  :550 recognizer pooler 8x32 sr0 on the P2P3 map; :556 image pooler 128x128 sr2).
+ * boxes [R,5] = (cx,cy,w,h,angle_deg), batch_idx [R]; level l has tensor feat[l] of
+ * [N,Hl,Wl,*] with pixel stride ld[l] and spatial scale scale[l]; C channels pooled.
+ * out is [R,PH,PW,*] with pixel stride ldy, first channel y_coff, channel step y_cstride. */
+typedef struct glass_roialign_desc {
+  int num_levels;
+  const float* feat[5];
+  int H[5], W[5], ld[5];
+  float scale[5];
+  int min_level;                 /* log2(1/scale[0]); level map of d2 assign_boxes_to_levels */
+  int C, PH, PW, sampling_ratio;
+  int ldy, y_coff, y_cstride;
+} glass_roialign_desc;
+
+int glass_roi_align_rotated(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R, float* out,
+                            glass_stream_t stream);
+
+/* ------------------------------------------------------------------ rotated-box proposals
+ * RRPN proposal selection for ONE pyramid level of a batch (d2 RRPN.predict_proposals +
+ * find_top_rrpn_proposals, reached from glass/modeling/meta_arch/glass_rcnn.py:87):
+ * per image, the `topk` highest objectness logits (descending, ties by lower index) are
+ * selected, their anchors generated analytically, deltas applied
+ * (Box2BoxTransformRotated), and written to out_boxes[n][slot_off + i] / out_scores /
+ * out_level.  logits: [N,H,W,A] (pixel stride ldl), deltas: [N,H,W,A*5] (pixel stride ldd).
+ * cell_anchors: [A,5] host-computed (w,h,angle used).  workspace: >= glass_rpn_topk_workspace(). */
+int64_t glass_rpn_topk_workspace(int N, int HWA);
+int glass_rpn_level_topk_decode(const float* logits, int ldl, const float* deltas, int ldd, int N, int H, int W, int A,
+                                int stride, float anchor_offset, const float* cell_anchors_dev, const float* weights5_host,
+                                int topk, int level_id, int slot_off, int slots_per_image, float* out_boxes,
+                                float* out_scores, int* out_level, void* workspace, int64_t workspace_bytes,
+                                glass_stream_t stream);
+
+/* Per image: drop non-finite, clip (|angle|<=1 deg only), drop empty, class/level-offset
+ * greedy rotated NMS (iou >= thr suppresses; CPU semantics of d2 nms_rotated), keep the
+ * first `post_topk` in descending score order.  Used for RPN (thr 0.7, post 100) and for
+ * the box head (glass/modeling/roi_heads/rotated_fast_rcnn.py:88-148: score filter,
+ * thr 0.35, top 100).  boxes [N,S,5], scores [N,S], cat [N,S] (level / class id),
+ * valid_count [N] (slots used per image; NULL = S).  image_hw [N,2] ints (h,w) on device.
+ * Inputs must already be sorted by descending score within each image unless
+ * `needs_sort` != 0.  Outputs: out_boxes [N,post_topk,5], out_scores [N,post_topk],
+ * out_index [N,post_topk] (slot index into the input), out_count [N].                    */
+int64_t glass_nms_workspace(int N, int S);
+int glass_rotated_nms_select(const float* boxes, const float* scores, const int* cat, const int* valid_count, int N, int S,
+                             const int* image_hw, float score_thresh, float nms_thresh, int post_topk, int needs_sort,
+                             int do_clip, float* out_boxes, float* out_scores, int* out_index, int* out_count,
+                             void* workspace, int64_t workspace_bytes, glass_stream_t stream);
+
+/* Box-head prediction decode (glass/modeling/roi_heads/rotated_fast_rcnn.py:335-342,
+ * 480-491): softmax over (K+1=2) class logits, apply_deltas with weights, orientation
+ * softmax -> (argmax, prob).  One class (K=1).  Outputs per proposal row.                */
+int glass_box_decode(const float* cls_logits, const float* deltas, const float* orient_logits, const float* proposals,
+                     int R, const float* weights5_host, float* out_boxes, float* out_fg_prob, float* out_orient2,
+                     glass_stream_t stream);
+
+/* ------------------------------------------------------------------ fusion attention
+ * MultiAspectGCAttention minus its out-conv (glass/modeling/fusion/fusion_modules.py:
+ * 91-154): x is the channel-INTERLEAVED cat(local,global) [R,HW,C] (C=512, channel 2i =
+ * local i, 2i+1 = global i, i.e. already x[:, order]); per head softmax(conv_mask) pooling,
+ * channel_add MLP (conv1x1 -> LayerNorm -> ReLU -> conv1x1) and the broadcast add are
+ * applied IN PLACE on x.  w_mask [C/heads], b_mask [1], w1 [P][C], b1 [P], ln_g/ln_b [P],
+ * w2 [C][P], b2 [C].                                                                     */
+int glass_gc_attention_inplace(float* x, int R, int HW, int C, int heads, int P, const float* w_mask, const float* b_mask,
+                               const float* w1, const float* b1, const float* ln_g, const float* ln_b, const float* w2,
+                               const float* b2, float* scratch /* R*(C+P) floats */, glass_stream_t stream);
+
+/* mean over H of an NHWC map: [R,H,W,C] -> [R,W,C]
+ * (BiLSTMBlockV2.forward, glass/modeling/recognition/recognizer_encoder.py:119).          */
+int glass_mean_over_h(const float* x, float* y, int R, int H, int W, int C, glass_stream_t stream);
+
+/* ------------------------------------------------------------------ recurrent encoder
+ * One bidirectional LSTM layer's recurrence (nn.LSTM gate order i,f,g,o; zero initial
+ * state; glass/modeling/recognition/recognizer_encoder.py:123-144).  The input projection
+ * xg = x @ W_ih^T + b_ih + b_hh for both directions is computed beforehand with
+ * glass_conv2d_nhwc: xg [R,T,2,4*Hd].  w_hh [2][4*Hd][Hd].  out [R,T,2*Hd] (fwd | bwd).  */
+int glass_bilstm_recurrence(const float* xg, const float* w_hh, float* out, int R, int T, int Hd, glass_stream_t stream);
+
+/* ------------------------------------------------------------------ attention decoder
+ * Greedy additive-attention GRU decoder (AttentionRecognitionHead.sample,
+ * glass/modeling/recognition/prediction_aster.py:63-99,247-266,291-302), all `max_len`
+ * steps on device with no host sync; the reference's batch-global early break (rows of
+ * steps after every RoI OF THE SAME IMAGE has emitted `eos` stay zero) is applied as a
+ * mask using roi_image [R] (image id per RoI, non-decreasing).
+ * x [R,T,D]; xproj [R,T,D] = xEmbed(x) precomputed with glass_conv2d_nhwc.
+ * Weights: sW [D][D], sB [D], wW [D], wB [1], emb [C][D], w_ih [3D][2D], w_hh [3D][D],
+ * b_ih [3D], b_hh [3D], fcW [C][D], fcB [C], temperature (host float).
+ * out [R,max_len,C] softmax probabilities.                                               */
+typedef struct glass_decoder_weights {
+  const float *sW, *sB, *wW, *wB, *emb, *w_ih, *w_hh, *b_ih, *b_hh, *fcW, *fcB;
+  float temperature;
+} glass_decoder_weights;
+int glass_attention_decode(const float* x, const float* xproj, const glass_decoder_weights* w, const int* roi_image, int R,
+                           int T, int D, int C, int max_len, int eos, float* out, glass_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLASS_HIP_H */

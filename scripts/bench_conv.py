@@ -1,0 +1,41 @@
+"""Micro-benchmark of glass_conv2d_nhwc on representative GLASS layers (GPU box only)."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "glass-text-spotting_amd"))
+import torch
+from glass_amd.ops import native as K
+
+dev = torch.device("cuda:0")
+LAYERS = [
+    # name, N, H, W, Cin, Cout, k, stride, pad
+    ("stem7x7", 8, 1024, 1024, 4, 64, 7, 2, 3),
+    ("res2.conv2 3x3 64", 8, 256, 256, 64, 64, 3, 1, 1),
+    ("res2.conv3 1x1 64->256", 8, 256, 256, 64, 256, 1, 1, 0),
+    ("res2.conv1 1x1 256->64", 8, 256, 256, 256, 64, 1, 1, 0),
+    ("res3.conv2 3x3 128", 8, 128, 128, 128, 128, 3, 1, 1),
+    ("res4.conv2 3x3 256", 8, 64, 64, 256, 256, 3, 1, 1),
+    ("res5.conv2 3x3 512", 8, 32, 32, 512, 512, 3, 1, 1),
+    ("res5.conv3 1x1 512->2048", 8, 32, 32, 512, 2048, 1, 1, 0),
+    ("fpn_out2 3x3 256 @256", 8, 256, 256, 256, 256, 3, 1, 1),
+    ("local l1 3x3 64 @64 R=256", 256, 64, 64, 64, 64, 3, 1, 1),
+    ("local l2 3x3 128 @32 R=256", 256, 32, 32, 128, 128, 3, 1, 1),
+    ("local l3 3x3 256 @16x33 R=256", 256, 16, 33, 256, 256, 3, 1, 1),
+    ("fusion out 3x3 512->256 R=256", 256, 8, 32, 512, 256, 3, 1, 1),
+    ("fc1 800x12544->2048", 800, 1, 1, 12544, 2048, 1, 1, 0),
+]
+for name, N, H, W, Cin, Cout, k, s, p in LAYERS:
+    x = torch.randn((N, H, W, Cin), device=dev)
+    w = torch.randn((Cout, k, k, Cin), device=dev) * 0.05
+    b = torch.randn((Cout,), device=dev)
+    y = K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    it = 5
+    e0.record()
+    for _ in range(it):
+        K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / it
+    flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * Cin * k * k
+    print(f"{name:36s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)

@@ -1,0 +1,143 @@
+"""GPU parity of the dense / gather kernels against fp32 references: torch CPU conv for the
+floating-point MFMA kernel (tolerance stated per test), the oracle C op for RoIAlignRotated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, relu, res_mode
+    (2, 20, 24, 64, 256, (3, 3), (1, 1), (1, 1), 1, 1),
+    (1, 33, 17, 128, 128, (3, 3), (1, 1), (1, 1), 0, 0),
+    (2, 16, 16, 256, 512, (1, 1), (2, 2), (0, 0), 0, 0),
+    (1, 40, 36, 4, 64, (7, 7), (2, 2), (3, 3), 1, 0),
+    (3, 16, 33, 256, 256, (2, 2), (2, 1), (0, 0), 1, 0),
+    (2, 8, 32, 256, 256, (2, 1), (2, 1), (0, 0), 2, 0),
+    (2, 32, 32, 4, 16, (3, 3), (1, 1), (1, 1), 1, 0),
+    (2, 32, 32, 16, 32, (3, 3), (1, 1), (1, 1), 1, 0),
+    (1, 24, 24, 256, 72, (1, 1), (1, 1), (0, 0), 0, 0),
+    (1, 16, 24, 512, 256, (1, 1), (1, 1), (0, 0), 0, 2),
+    (2, 8, 32, 512, 256, (3, 3), (1, 1), (1, 1), 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_torch(case):
+    from glass_amd.ops import native as K
+    N, H, W, Cin, Cout, k, s, p, relu, res_mode = case
+    dev = _dev()
+    x = _rand((N, Cin, H, W), 1)
+    w = _rand((Cout, Cin, k[0], k[1]), 2, (2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    b = _rand((Cout,), 3, 0.1)
+    if Cin == 4:
+        x[:, 3] = 0
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    res = None
+    if res_mode == 1:
+        res = _rand(tuple(ref.shape), 4)
+        ref = ref + res
+    elif res_mode == 2:
+        res = _rand((N, Cout, ref.shape[2] // 2, ref.shape[3] // 2), 4)
+        ref = ref + F.interpolate(res, scale_factor=2.0, mode="nearest")
+    if relu == 1:
+        ref = F.relu(ref)
+    elif relu == 2:
+        extra = _rand(tuple(ref.shape), 5)
+        ref = F.relu(ref) + extra
+        res, res_mode = extra, 1
+    y = K.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), b.to(dev),
+                      stride=s, padding=p, relu=relu,
+                      residual=None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev), res_mode=res_mode)
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2)
+    # fp32 MFMA is an exact-fp32 fma chain; only the summation order differs from MKL-DNN
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_linear_big_k_and_interleaved_output():
+    from glass_amd.ops import native as K
+    dev = _dev()
+    x = _rand((100, 12544), 1)
+    w = _rand((2048, 12544), 2, (2.0 / 12544) ** 0.5)
+    b = _rand((2048,), 3, 0.1)
+    ref = F.relu(F.linear(x, w, b))
+    y = K.linear(x.to(dev), w.to(dev), b.to(dev), relu=1)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=5e-4)
+    # channel-interleaved output (used to build the fusion input x[:, order] for free)
+    xs = _rand((2, 8, 32, 256), 4)
+    ws = _rand((256, 1, 1, 256), 5, 0.1)
+    out = torch.zeros((2, 8, 32, 512), device=dev)
+    K.conv2d_nhwc(xs.to(dev), ws.to(dev), None, out=out, out_coff=1, out_cstride=2)
+    ref2 = F.conv2d(xs.permute(0, 3, 1, 2), ws.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    o = out.cpu()
+    np.testing.assert_allclose(o[..., 1::2].numpy(), ref2.numpy(), rtol=1e-4, atol=1e-4)
+    assert (o[..., 0::2] == 0).all()
+
+
+def test_maxpool_matches_torch():
+    from glass_amd.ops import native as K
+    dev = _dev()
+    for (k, s, p, shape) in (((3, 3), (2, 2), (1, 1), (2, 64, 30, 34)), ((2, 2), (2, 2), (0, 0), (3, 32, 16, 16)),
+                             ((2, 2), (2, 1), (0, 1), (2, 128, 32, 32))):
+        x = _rand(shape, 7)
+        ref = F.max_pool2d(x, k, s, p)
+        y = K.maxpool2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), k, s, p)
+        assert torch.equal(y.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("cfgk", ["box", "rec", "img"])
+def test_roi_align_rotated_matches_oracle(cfgk):
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import make_boxes
+    from oracle import d2ops
+    dev = _dev()
+    if cfgk == "box":
+        feats = [_rand((2, 256, 64 >> i, 80 >> i), 10 + i) for i in range(5)]
+        scales = [1.0 / (4 << i) for i in range(5)]
+        out_size, sr = (7, 7), 2
+    elif cfgk == "rec":
+        feats, scales, out_size, sr = [_rand((2, 256, 64, 80), 20)], [0.25], (8, 32), 0
+    else:
+        feats, scales, out_size, sr = [_rand((2, 4, 256, 320), 30)], [1.0], (128, 128), 2
+    boxes = [make_boxes(i, 9, 256, 320) for i in range(2)]
+    boxes[0][0] = torch.tensor([5.0, 4.0, 60.0, 30.0, 0.5])      # partly outside
+    boxes[0][1] = torch.tensor([160.0, 128.0, 700.0, 400.0, 33.0])  # larger than the image -> top level
+    boxes[1][0] = torch.tensor([100.0, 100.0, 3.0, 2.0, -90.0])   # tiny -> lowest level, gh=gw=1 when sr=0
+    ref = d2ops.roi_pooler(feats, scales, boxes, out_size, sr)
+    bcat = torch.cat(boxes).contiguous()
+    bidx = torch.cat([torch.full((len(b),), i, dtype=torch.int32) for i, b in enumerate(boxes)])
+    y = K.roi_align_rotated([f.permute(0, 2, 3, 1).contiguous().to(dev) for f in feats], scales, bcat.to(dev), bidx.to(dev),
+                            out_size, sr)
+    np.testing.assert_allclose(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_preprocess_and_resize():
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import make_image
+    dev = _dev()
+    img = make_image(0, 37, 53)
+    chw = K.image_u8hwc_to_chw(img.to(dev), (37, 53))
+    assert torch.equal(chw.cpu(), img.permute(2, 0, 1).float())
+    up = K.image_u8hwc_to_chw(img.to(dev), (44, 64))
+    ref = F.interpolate(img.permute(2, 0, 1).float()[None], size=(44, 64), mode="bilinear", align_corners=False)[0]
+    np.testing.assert_allclose(up.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-3)
+    batch = torch.full((2, 64, 64, 4), 7.0, device=dev)
+    mean, std = [103.53, 116.28, 123.675], [1.0, 1.0, 1.0]
+    K.preprocess_image(chw, mean, std, batch, 1)
+    b = batch.cpu()
+    exp = torch.zeros(64, 64, 4)
+    exp[:37, :53, :3] = (img.float() - torch.tensor(mean))
+    assert torch.equal(b[1], exp) and (b[0] == 7).all()
