@@ -1,0 +1,559 @@
+// Rotated-box proposal machinery: per-level top-k + anchor decode, rotated IoU, blocked greedy
+// NMS, box-head decode.  These stages are latency-bound integer/compare work, not GEMMs:
+// one workgroup (1024 threads = 16 wavefronts) per image keeps the whole candidate list in
+// LDS, uses LDS radix histograms for the top-k select and 64-wide ballots' worth of
+// candidates per NMS chunk (one wavefront-width bitmask row per candidate).
+#include "common.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ u32 float_key(float f) {
+  // order-preserving map float -> uint (larger float => larger key); -0 < +0 is harmless here
+  u32 u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(u32 k) {
+  u32 u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// descending bitonic sort of `npad` (power of two) u64 in LDS by all threads of the block
+__device__ void bitonic_sort_desc(u64* a, int npad) {
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const u64 x = a[i], y = a[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { a[i] = y; a[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RPN: top-k + decode
+constexpr int TOPK_MAX = 2048;
+constexpr float SCALE_CLAMP = 4.135166556742356f;  // log(1000/16)
+
+struct RpnParams {
+  const float* logits; const float* deltas; const float* cell;
+  int ldl, ldd, N, H, W, A, stride;
+  float anchor_offset, wx, wy, ww, wh, wa;
+  int topk, level_id, slot_off, slots;
+  float* out_boxes; float* out_scores; int* out_level;
+};
+
+__device__ __forceinline__ float floor_mod(float a, float b) {  // torch.remainder semantics
+  float m = fmodf(a, b);
+  if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
+  return m;
+}
+
+__global__ __launch_bounds__(1024) void rpn_topk_decode_kernel(RpnParams p) {
+  __shared__ u32 hist[256];
+  __shared__ u64 sel[TOPK_MAX];
+  __shared__ u64 s_prefix;
+  __shared__ int s_krem, s_done, s_cnt;
+  const int n = blockIdx.x;
+  const int total = p.H * p.W * p.A;
+  const int k = p.topk < total ? p.topk : total;
+  const float* lg = p.logits + (long)n * p.H * p.W * p.ldl;
+  const bool dense = (p.ldl == p.A);   // logits contiguous -> flat index == memory index
+
+  auto composite = [&](int i) -> u64 {
+    const float v = dense ? lg[i] : lg[(long)(i / p.A) * p.ldl + (i % p.A)];
+    // NaN sorts as the largest value in torch.sort(descending) -> give it the top key
+    const u32 key = (v != v) ? 0xffffffffu : float_key(v);
+    return ((u64)key << 32) | (u64)(0xffffffffu - (u32)i);   // ties: lower index first
+  };
+
+  // MSD radix select on the 64-bit composite (8 bits / pass); all composites are distinct,
+  // so the k-th largest is unique.  Stops early once a whole bucket is taken.
+  if (threadIdx.x == 0) { s_prefix = 0; s_krem = k; s_done = 0; }
+  __syncthreads();
+  u64 thr = 0;   // select all composites >= thr
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const u64 prefix = s_prefix;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const u64 c = composite(i);
+      if (pass == 0 || (c >> (shift + 8)) == prefix) atomicAdd(&hist[(u32)(c >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int krem = s_krem, b = 255;
+      u32 cum = 0;
+      for (; b >= 0; --b) {
+        if (cum + hist[b] >= (u32)krem) break;
+        cum += hist[b];
+      }
+      // bucket b holds the k-th element; `cum` elements are in strictly higher buckets
+      s_prefix = (prefix << 8) | (u64)b;
+      s_krem = krem - (int)cum;
+      if (hist[b] == (u32)(krem - (int)cum)) s_done = 1;   // take the whole bucket
+    }
+    __syncthreads();
+    thr = s_prefix << shift;
+    if (s_done || pass == 7) break;
+  }
+  // compaction (unordered) + sort
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  int npad = 1;
+  while (npad < k) npad <<= 1;
+  for (int i = threadIdx.x; i < npad; i += blockDim.x) sel[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const u64 c = composite(i);
+    if (c >= thr) {
+      const int slot = atomicAdd(&s_cnt, 1);
+      if (slot < TOPK_MAX) sel[slot] = c;
+    }
+  }
+  __syncthreads();
+  bitonic_sort_desc(sel, npad);
+  // decode the selected anchors
+  for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    const u64 c = sel[j];
+    const int i = (int)(0xffffffffu - (u32)(c & 0xffffffffu));
+    const int a = i % p.A;
+    const int cellidx = i / p.A;
+    const int w = cellidx % p.W, h = cellidx / p.W;
+    const float score = dense ? lg[i] : lg[(long)cellidx * p.ldl + a];
+    const float* d = p.deltas + ((long)n * p.H * p.W + cellidx) * p.ldd + a * 5;
+    const float acx = (float)w * (float)p.stride + p.anchor_offset * (float)p.stride;
+    const float acy = (float)h * (float)p.stride + p.anchor_offset * (float)p.stride;
+    const float aw = p.cell[a * 5 + 2], ah = p.cell[a * 5 + 3], aa = p.cell[a * 5 + 4];
+    const float dx = d[0] / p.wx, dy = d[1] / p.wy;
+    float dw = d[2] / p.ww, dh = d[3] / p.wh;
+    const float da = d[4] / p.wa;
+    dw = fminf(dw, SCALE_CLAMP);
+    dh = fminf(dh, SCALE_CLAMP);
+    float* ob = p.out_boxes + ((long)n * p.slots + p.slot_off + j) * 5;
+    ob[0] = dx * aw + acx;
+    ob[1] = dy * ah + acy;
+    ob[2] = expf(dw) * aw;
+    ob[3] = expf(dh) * ah;
+    const float pa = da * 180.0f / 3.14159265358979323846f + aa;
+    ob[4] = floor_mod(pa + 180.0f, 360.0f) - 180.0f;
+    p.out_scores[(long)n * p.slots + p.slot_off + j] = score;
+    p.out_level[(long)n * p.slots + p.slot_off + j] = p.level_id;
+  }
+}
+
+extern "C" int glass_rpn_level_topk_decode(const float* logits, int ldl, const float* deltas, int ldd, int N, int H, int W,
+                                           int A, int stride, float anchor_offset, const float* cell_anchors_dev,
+                                           const float* weights5_host, int topk, int level_id, int slot_off,
+                                           int slots_per_image, float* out_boxes, float* out_scores, int* out_level,
+                                           glass_stream_t stream) {
+  GLASS_CHECK_ARG(logits && deltas && cell_anchors_dev && weights5_host && out_boxes && out_scores && out_level,
+                  "glass_rpn_level_topk_decode: null pointer");
+  GLASS_CHECK_ARG(topk > 0 && topk <= TOPK_MAX, "glass_rpn_level_topk_decode: topk=%d (max %d)", topk, TOPK_MAX);
+  GLASS_CHECK_ARG(H > 0 && W > 0 && A > 0 && ldl >= A && ldd >= 5 * A, "glass_rpn_level_topk_decode: bad dims");
+  const int k = topk < H * W * A ? topk : H * W * A;
+  GLASS_CHECK_ARG(slot_off >= 0 && slot_off + k <= slots_per_image, "glass_rpn_level_topk_decode: slots overflow");
+  if (N == 0) return GLASS_OK;
+  RpnParams p;
+  p.logits = logits; p.deltas = deltas; p.cell = cell_anchors_dev; p.ldl = ldl; p.ldd = ldd; p.N = N; p.H = H; p.W = W;
+  p.A = A; p.stride = stride; p.anchor_offset = anchor_offset;
+  p.wx = weights5_host[0]; p.wy = weights5_host[1]; p.ww = weights5_host[2]; p.wh = weights5_host[3]; p.wa = weights5_host[4];
+  p.topk = topk; p.level_id = level_id; p.slot_off = slot_off; p.slots = slots_per_image;
+  p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_level = out_level;
+  hipLaunchKernelGGL(rpn_topk_decode_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, p);
+  GLASS_CHECK_LAUNCH("glass_rpn_level_topk_decode");
+  return GLASS_OK;
+}
+
+// ------------------------------------------------------------------ rotated IoU (d2 box_iou_rotated_utils.h)
+struct Pt { float x, y; };
+__device__ __forceinline__ Pt psub(Pt a, Pt b) { return Pt{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ float dot2(Pt a, Pt b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ float cross2(Pt a, Pt b) { return a.x * b.y - b.x * a.y; }
+
+// box = (cx, cy, w, h) + half-extent cos/sin (cos(theta)*0.5, sin(theta)*0.5 computed in double like d2)
+struct RBox { float cx, cy, w, h, c2, s2; };
+
+__device__ __forceinline__ void rbox_vertices(float cx, float cy, const RBox& b, Pt* pts) {
+  pts[0].x = cx + b.s2 * b.h + b.c2 * b.w;
+  pts[0].y = cy + b.c2 * b.h - b.s2 * b.w;
+  pts[1].x = cx - b.s2 * b.h + b.c2 * b.w;
+  pts[1].y = cy - b.c2 * b.h - b.s2 * b.w;
+  pts[2].x = 2 * cx - pts[0].x;
+  pts[2].y = 2 * cy - pts[0].y;
+  pts[3].x = 2 * cx - pts[1].x;
+  pts[3].y = 2 * cy - pts[1].y;
+}
+
+__device__ __forceinline__ bool hull_less(Pt A, Pt B) {
+  const float t = cross2(A, B);
+  if (fabsf(t) < 1e-6f) return dot2(A, A) < dot2(B, B);
+  return t > 0;
+}
+
+__device__ float rotated_iou(const RBox& r1, const RBox& r2) {
+  const float area1 = r1.w * r1.h, area2 = r2.w * r2.h;
+  if (area1 < 1e-14f || area2 < 1e-14f) return 0.f;
+  const float sx = (r1.cx + r2.cx) / 2.0f, sy = (r1.cy + r2.cy) / 2.0f;
+  Pt p1[4], p2[4];
+  rbox_vertices(r1.cx - sx, r1.cy - sy, r1, p1);
+  rbox_vertices(r2.cx - sx, r2.cy - sy, r2, p2);
+  Pt v1[4], v2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v1[i] = psub(p1[(i + 1) & 3], p1[i]);
+    v2[i] = psub(p2[(i + 1) & 3], p2[i]);
+  }
+  Pt ip[24];
+  int num = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float det = cross2(v2[j], v1[i]);
+      if (fabsf(det) <= 1e-14f) continue;
+      const Pt v12 = psub(p2[j], p1[i]);
+      const float t1 = cross2(v2[j], v12) / det;
+      const float t2 = cross2(v1[i], v12) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
+        ip[num].x = p1[i].x + v1[i].x * t1;
+        ip[num].y = p1[i].y + v1[i].y * t1;
+        ++num;
+      }
+    }
+  {
+    const Pt AB = v2[0], DA = v2[3];
+    const float ABdotAB = dot2(AB, AB), ADdotAD = dot2(DA, DA);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const Pt AP = psub(p1[i], p2[0]);
+      const float APdotAB = dot2(AP, AB), APdotAD = -dot2(AP, DA);
+      if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) ip[num++] = p1[i];
+    }
+  }
+  {
+    const Pt AB = v1[0], DA = v1[3];
+    const float ABdotAB = dot2(AB, AB), ADdotAD = dot2(DA, DA);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const Pt AP = psub(p2[i], p1[0]);
+      const float APdotAB = dot2(AP, AB), APdotAD = -dot2(AP, DA);
+      if (APdotAB >= 0 && APdotAD >= 0 && APdotAB <= ABdotAB && APdotAD <= ADdotAD) ip[num++] = p2[i];
+    }
+  }
+  if (num <= 2) return 0.f;
+  // Graham scan (CPU variant of d2's convex_hull_graham, shift_to_zero = true)
+  int t = 0;
+  for (int i = 1; i < num; ++i)
+    if (ip[i].y < ip[t].y || (ip[i].y == ip[t].y && ip[i].x < ip[t].x)) t = i;
+  const Pt start = ip[t];
+  Pt q[24];
+  for (int i = 0; i < num; ++i) q[i] = psub(ip[i], start);
+  { const Pt tmp = q[0]; q[0] = q[t]; q[t] = tmp; }
+  for (int i = 2; i < num; ++i) {
+    const Pt key = q[i];
+    int j = i - 1;
+    while (j >= 1 && hull_less(key, q[j])) { q[j + 1] = q[j]; --j; }
+    q[j + 1] = key;
+  }
+  int k;
+  for (k = 1; k < num; ++k)
+    if (dot2(q[k], q[k]) > 1e-8f) break;
+  float inter = 0.f;
+  if (k < num) {
+    q[1] = q[k];
+    int m = 2;
+    for (int i = k + 1; i < num; ++i) {
+      while (m > 1 && cross2(psub(q[i], q[m - 2]), psub(q[m - 1], q[m - 2])) >= 0) --m;
+      q[m++] = q[i];
+    }
+    if (m > 2) {
+      float area = 0.f;
+      for (int i = 1; i < m - 1; ++i) area += fabsf(cross2(psub(q[i], q[0]), psub(q[i + 1], q[0])));
+      inter = area / 2.0f;
+    }
+  }
+  return inter / (area1 + area2 - inter);
+}
+
+__device__ __forceinline__ RBox make_rbox(float cx, float cy, float w, float h, float a) {
+  const double theta = (double)a * 0.01745329251;
+  RBox b;
+  b.cx = cx; b.cy = cy; b.w = w; b.h = h;
+  b.c2 = (float)cos(theta) * 0.5f;
+  b.s2 = (float)sin(theta) * 0.5f;
+  return b;
+}
+
+// pairwise IoU matrix (post-processing's pairwise_iou_rotated, glass/structures/boxes.py:33)
+__global__ void pairwise_iou_kernel(const float* b1, int n1, const float* b2, int n2, float* out) {
+  const long total = (long)n1 * n2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / n2), j = (int)(idx % n2);
+    const float* x = b1 + 5 * i;
+    const float* y = b2 + 5 * j;
+    out[idx] = rotated_iou(make_rbox(x[0], x[1], x[2], x[3], x[4]), make_rbox(y[0], y[1], y[2], y[3], y[4]));
+  }
+}
+
+extern "C" int glass_pairwise_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2, float* out,
+                                          glass_stream_t stream) {
+  if (n1 == 0 || n2 == 0) return GLASS_OK;
+  GLASS_CHECK_ARG(boxes1 && boxes2 && out, "glass_pairwise_iou_rotated: null pointer");
+  const long total = (long)n1 * n2;
+  long g = (total + 127) / 128;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(pairwise_iou_kernel, dim3((unsigned)g), dim3(128), 0, (hipStream_t)stream, boxes1, n1, boxes2, n2, out);
+  GLASS_CHECK_LAUNCH("glass_pairwise_iou_rotated");
+  return GLASS_OK;
+}
+
+// ------------------------------------------------------------------ filter + sort + greedy NMS
+constexpr int NMS_SMAX = 8192;
+constexpr int NMS_KEEP_MAX = 1024;
+constexpr int NMS_THREADS = 1024;
+
+struct NmsParams {
+  const float* boxes; const float* scores; const int* cat; const int* valid_count; const int* image_hw;
+  int N, S;
+  float score_thresh, nms_thresh;
+  int post_topk, flags;
+  float* out_boxes; float* out_scores; int* out_index; int* out_count;
+};
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_select_kernel(NmsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  // carve: sorted composites [npad] u64 | kept boxes | chunk boxes | masks
+  const int n = blockIdx.x;
+  const int S = p.S;
+  int npad = 1;
+  while (npad < S) npad <<= 1;
+  u64* order = reinterpret_cast<u64*>(dyn_smem);
+  RBox* kept = reinterpret_cast<RBox*>(order + npad);
+  RBox* chunk = kept + NMS_KEEP_MAX;
+  u64* cmask = reinterpret_cast<u64*>(chunk + 64);
+  int* csup = reinterpret_cast<int*>(cmask + 64);
+  int* cslot = csup + 64;
+  __shared__ float red_max[NMS_THREADS / 64], red_min[NMS_THREADS / 64];
+  __shared__ float s_span;
+  __shared__ int s_nvalid, s_nkept, s_stop;
+
+  const float* boxes = p.boxes + (long)n * S * 5;
+  const float* scores = p.scores + (long)n * S;
+  const int* cat = p.cat ? p.cat + (long)n * S : nullptr;
+  const int cnt = p.valid_count ? min(p.valid_count[n], S) : S;
+  const float img_h = (float)p.image_hw[2 * n], img_w = (float)p.image_hw[2 * n + 1];
+
+  // clipped box of a slot (recomputed where needed; 5 floats, cheap)
+  auto load_box = [&](int s, float* b) {
+    b[0] = boxes[5 * s]; b[1] = boxes[5 * s + 1]; b[2] = boxes[5 * s + 2]; b[3] = boxes[5 * s + 3]; b[4] = boxes[5 * s + 4];
+    if (p.flags & GLASS_NMS_CLIP) {
+      // RotatedBoxes.clip: normalise angle, then clip only nearly-horizontal boxes
+      b[4] = floor_mod(b[4] + 180.0f, 360.0f) - 180.0f;
+      if (fabsf(b[4]) <= 1.0f) {
+        float x1 = b[0] - b[2] / 2.0f, y1 = b[1] - b[3] / 2.0f, x2 = b[0] + b[2] / 2.0f, y2 = b[1] + b[3] / 2.0f;
+        x1 = fminf(fmaxf(x1, 0.f), img_w); x2 = fminf(fmaxf(x2, 0.f), img_w);
+        y1 = fminf(fmaxf(y1, 0.f), img_h); y2 = fminf(fmaxf(y2, 0.f), img_h);
+        b[0] = (x1 + x2) / 2.0f;
+        b[1] = (y1 + y2) / 2.0f;
+        b[2] = fminf(b[2], x2 - x1);
+        b[3] = fminf(b[3], y2 - y1);
+      }
+    }
+  };
+
+  // 1. validity, sort keys, coordinate span for the category offsets
+  float lmax = -INFINITY, lmin = INFINITY;
+  for (int s = threadIdx.x; s < npad; s += blockDim.x) {
+    u64 c = 0;
+    if (s < cnt) {
+      const float sc = scores[s];
+      bool ok = isfinite(sc) && isfinite(boxes[5 * s]) && isfinite(boxes[5 * s + 1]) && isfinite(boxes[5 * s + 2]) &&
+                isfinite(boxes[5 * s + 3]) && isfinite(boxes[5 * s + 4]);
+      if (ok) {
+        float b[5];
+        load_box(s, b);
+        if ((p.flags & GLASS_NMS_DROP_EMPTY) && !(b[2] > 0.f && b[3] > 0.f)) ok = false;
+        if (!(sc > p.score_thresh)) ok = false;
+        if (ok) {
+          c = ((u64)float_key(sc) << 32) | (u64)(0xffffffffu - (u32)s);
+          const float ext = fmaxf(b[2], b[3]) / 2.0f;
+          lmax = fmaxf(lmax, fmaxf(b[0], b[1]) + ext);
+          lmin = fminf(lmin, fminf(b[0], b[1]) - ext);
+        }
+      }
+    }
+    order[s] = c;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    lmin = fminf(lmin, __shfl_xor(lmin, off));
+  }
+  if ((threadIdx.x & 63) == 0) { red_max[threadIdx.x >> 6] = lmax; red_min[threadIdx.x >> 6] = lmin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mx = -INFINITY, mn = INFINITY;
+    for (int i = 0; i < NMS_THREADS / 64; ++i) { mx = fmaxf(mx, red_max[i]); mn = fminf(mn, red_min[i]); }
+    s_span = mx - mn + 1.0f;
+    s_nkept = 0;
+    s_stop = 0;
+  }
+  __syncthreads();
+  bitonic_sort_desc(order, npad);
+  // number of valid = first zero composite (valid composites are never 0: key has the top bit
+  // set for non-negative scores, and for negative scores the index part is non-zero unless
+  // s = 2^32-1)
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = npad;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (order[mid] != 0) lo = mid + 1; else hi = mid; }
+    s_nvalid = lo;
+  }
+  __syncthreads();
+  const int nvalid = s_nvalid;
+  const float span = s_span;
+  const int keep_cap = p.post_topk < NMS_KEEP_MAX ? p.post_topk : NMS_KEEP_MAX;
+
+  // 2. blocked greedy NMS over chunks of 64 sorted candidates
+  for (int c0 = 0; c0 < nvalid; c0 += 64) {
+    const int csize = min(64, nvalid - c0);
+    if (threadIdx.x < 64) {
+      cmask[threadIdx.x] = 0;
+      csup[threadIdx.x] = 0;
+      if ((int)threadIdx.x < csize) {
+        const int s = (int)(0xffffffffu - (u32)(order[c0 + threadIdx.x] & 0xffffffffu));
+        float b[5];
+        load_box(s, b);
+        const float off = cat ? (float)cat[s] * span : 0.f;
+        chunk[threadIdx.x] = make_rbox(b[0] + off, b[1] + off, b[2], b[3], b[4]);
+        cslot[threadIdx.x] = s;
+      }
+    }
+    __syncthreads();
+    const int nk = s_nkept;
+    // (a) candidates vs already kept boxes
+    for (int pr = threadIdx.x; pr < csize * nk; pr += blockDim.x) {
+      const int j = pr / nk, i = pr - j * nk;
+      if (rotated_iou(kept[i], chunk[j]) >= p.nms_thresh) csup[j] = 1;
+    }
+    // (b) intra-chunk pairs i < j
+    for (int pr = threadIdx.x; pr < csize * csize; pr += blockDim.x) {
+      const int i = pr / csize, j = pr - i * csize;
+      if (i < j && rotated_iou(chunk[i], chunk[j]) >= p.nms_thresh) atomicOr(&cmask[i], 1ull << j);
+    }
+    __syncthreads();
+    // (c) serial resolve inside the chunk
+    if (threadIdx.x == 0) {
+      u64 sup = 0;
+      int kcount = nk;
+      for (int i = 0; i < csize; ++i) {
+        if (csup[i] || ((sup >> i) & 1ull)) continue;
+        if (kcount >= keep_cap) { s_stop = 1; break; }
+        kept[kcount] = chunk[i];
+        const int s = cslot[i];
+        float b[5];
+        load_box(s, b);
+        float* ob = p.out_boxes + ((long)n * p.post_topk + kcount) * 5;
+        ob[0] = b[0]; ob[1] = b[1]; ob[2] = b[2]; ob[3] = b[3]; ob[4] = b[4];
+        p.out_scores[(long)n * p.post_topk + kcount] = scores[s];
+        p.out_index[(long)n * p.post_topk + kcount] = s;
+        ++kcount;
+        sup |= cmask[i];
+      }
+      if (kcount >= keep_cap) s_stop = 1;
+      s_nkept = kcount;
+    }
+    __syncthreads();
+    if (s_stop) break;
+  }
+  if (threadIdx.x == 0) p.out_count[n] = s_nkept;
+}
+
+extern "C" int glass_rotated_nms_select(const float* boxes, const float* scores, const int* cat, const int* valid_count,
+                                        int N, int S, const int* image_hw, float score_thresh, float nms_thresh,
+                                        int post_topk, int flags, float* out_boxes, float* out_scores, int* out_index,
+                                        int* out_count, glass_stream_t stream) {
+  GLASS_CHECK_ARG(out_boxes && out_scores && out_index && out_count && image_hw, "glass_rotated_nms_select: null pointer");
+  GLASS_CHECK_ARG(S >= 0 && S <= NMS_SMAX, "glass_rotated_nms_select: S=%d (max %d)", S, NMS_SMAX);
+  GLASS_CHECK_ARG(post_topk > 0 && post_topk <= NMS_KEEP_MAX, "glass_rotated_nms_select: post_topk=%d (max %d)", post_topk,
+                  NMS_KEEP_MAX);
+  if (N == 0) return GLASS_OK;
+  if (S == 0) {
+    hipError_t e = hipMemsetAsync(out_count, 0, sizeof(int) * N, (hipStream_t)stream);
+    if (e != hipSuccess) { glass_set_error("glass_rotated_nms_select: memset: %s", hipGetErrorString(e)); return GLASS_EHIP; }
+    return GLASS_OK;
+  }
+  GLASS_CHECK_ARG(boxes && scores, "glass_rotated_nms_select: null boxes");
+  int npad = 1;
+  while (npad < S) npad <<= 1;
+  const size_t smem = sizeof(u64) * npad + sizeof(RBox) * (NMS_KEEP_MAX + 64) + sizeof(u64) * 64 + sizeof(int) * 128;
+  NmsParams p;
+  p.boxes = boxes; p.scores = scores; p.cat = cat; p.valid_count = valid_count; p.image_hw = image_hw; p.N = N; p.S = S;
+  p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.post_topk = post_topk; p.flags = flags;
+  p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_index = out_index; p.out_count = out_count;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nms_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_select_kernel, dim3(N), dim3(NMS_THREADS), smem, (hipStream_t)stream, p);
+  GLASS_CHECK_LAUNCH("glass_rotated_nms_select");
+  return GLASS_OK;
+}
+
+// ------------------------------------------------------------------ box-head decode
+__global__ void box_decode_kernel(const float* cls, const float* deltas, const float* orient, const float* props, int R,
+                                  float wx, float wy, float ww, float wh, float wa, float* out_boxes, float* out_fg,
+                                  float* out_orient) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  // softmax over (fg, bg) logits; fg is column 0 (rotated_fast_rcnn.py:109 drops the LAST column)
+  const float l0 = cls[2 * r], l1 = cls[2 * r + 1];
+  const float m = fmaxf(l0, l1);
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+  out_fg[r] = e0 / (e0 + e1);
+  const float* d = deltas + 5 * r;
+  const float* b = props + 5 * r;
+  const float dx = d[0] / wx, dy = d[1] / wy;
+  float dw = d[2] / ww, dh = d[3] / wh;
+  const float da = d[4] / wa;
+  dw = fminf(dw, SCALE_CLAMP);
+  dh = fminf(dh, SCALE_CLAMP);
+  float* ob = out_boxes + 5 * r;
+  ob[0] = dx * b[2] + b[0];
+  ob[1] = dy * b[3] + b[1];
+  ob[2] = expf(dw) * b[2];
+  ob[3] = expf(dh) * b[3];
+  const float pa = da * 180.0f / 3.14159265358979323846f + b[4];
+  ob[4] = floor_mod(pa + 180.0f, 360.0f) - 180.0f;
+  // orientation softmax over 4 logits -> (argmax, max prob); first max wins like torch.max
+  const float* o = orient + 4 * r;
+  float om = fmaxf(fmaxf(o[0], o[1]), fmaxf(o[2], o[3]));
+  float e[4], sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { e[i] = expf(o[i] - om); sum += e[i]; }
+  int am = 0;
+  float pm = e[0] / sum;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) { const float pi = e[i] / sum; if (pi > pm) { pm = pi; am = i; } }
+  out_orient[2 * r] = (float)am;
+  out_orient[2 * r + 1] = pm;
+}
+
+extern "C" int glass_box_decode(const float* cls_logits, const float* deltas, const float* orient_logits,
+                                const float* proposals, int R, const float* weights5_host, float* out_boxes,
+                                float* out_fg_prob, float* out_orient2, glass_stream_t stream) {
+  if (R == 0) return GLASS_OK;
+  GLASS_CHECK_ARG(cls_logits && deltas && orient_logits && proposals && weights5_host && out_boxes && out_fg_prob && out_orient2,
+                  "glass_box_decode: null pointer");
+  hipLaunchKernelGGL(box_decode_kernel, dim3(cdiv(R, 128)), dim3(128), 0, (hipStream_t)stream, cls_logits, deltas,
+                     orient_logits, proposals, R, weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3],
+                     weights5_host[4], out_boxes, out_fg_prob, out_orient2);
+  GLASS_CHECK_LAUNCH("glass_box_decode");
+  return GLASS_OK;
+}

@@ -1,0 +1,89 @@
+"""Global-to-local fusion modules on HIP kernels.
+
+Mirrors reference glass/modeling/fusion/fusion_modules.py: `MultiAspectGCAttention` (:22-157,
+pooling 'att', fusion 'channel_add') and `P2P3Fusion` (:250-286), plus the registry/builder
+(:10-18).  Unused variants (SimpleAttention, LocalOnly, Conv1x1) are out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from ...utils.module import InferenceModule
+
+from ...checkpoint import dev, fold_conv
+from ...ops import native as K
+from ...utils.registry import Registry
+
+HYBRID_FEATURE_FUSION_REGISTRY = Registry("HYBRID_FEATURE_FUSION")
+
+
+def build_hybrid_feature_fusion(cfg, input_shape):
+    name = cfg.MODEL.HYBRID_FUSION.NAME
+    return HYBRID_FEATURE_FUSION_REGISTRY.get(name)(cfg, input_shape)
+
+
+@HYBRID_FEATURE_FUSION_REGISTRY.register()
+class MultiAspectGCAttention(InferenceModule):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        self.inplanes = cfg.MODEL.LOCAL_FEATURE_EXTRACTOR.NUM_FEATURES + input_shape.channels
+        self.ratio = cfg.MODEL.HYBRID_FUSION.RATIO
+        self.headers = cfg.MODEL.HYBRID_FUSION.HEADERS
+        self.outplane = cfg.MODEL.HYBRID_FUSION.NUM_FEATURES
+        self.fusion_type = cfg.MODEL.HYBRID_FUSION.FUSION_TYPE
+        assert self.fusion_type == "channel_add", "only channel_add is built (all reference configs)"
+        self.planes = int(self.inplanes * self.ratio)
+        self.w: Dict[str, torch.Tensor] = {}
+
+    def import_weights(self, sd, device, prefix: str) -> None:
+        w = {}
+        w["w_mask"] = dev(sd[prefix + "conv_mask.weight"].reshape(-1), device)
+        w["b_mask"] = dev(sd[prefix + "conv_mask.bias"].reshape(-1), device)
+        w["w1"] = dev(sd[prefix + "channel_add_conv.0.weight"].reshape(self.planes, self.inplanes), device)
+        w["b1"] = dev(sd[prefix + "channel_add_conv.0.bias"], device)
+        w["ln_g"] = dev(sd[prefix + "channel_add_conv.1.weight"].reshape(-1), device)
+        w["ln_b"] = dev(sd[prefix + "channel_add_conv.1.bias"].reshape(-1), device)
+        w["w2"] = dev(sd[prefix + "channel_add_conv.3.weight"].reshape(self.inplanes, self.planes), device)
+        w["b2"] = dev(sd[prefix + "channel_add_conv.3.bias"], device)
+        w["out"] = fold_conv(sd, prefix + "out", None, device)
+        self.w = w
+
+    def forward_interleaved(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [R,8,32,512] NHWC, channels already interleaved (x[:, order] of the reference,
+        fusion_modules.py:50-53,131); modified in place.  Returns [R,8,32,256]."""
+        w = self.w
+        K.gc_attention_inplace(x, self.headers, w["w_mask"], w["b_mask"], w["w1"], w["b1"], w["ln_g"], w["ln_b"],
+                               w["w2"], w["b2"])
+        return K.conv2d_nhwc(x, *w["out"], padding=1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """reference convention: logical NCHW cat(local, global) [R,512,8,32] -> [R,256,8,32]."""
+        C = x.shape[1]
+        order = torch.zeros(C, dtype=torch.long)
+        order[0::2] = torch.arange(C)[: C // 2]
+        order[1::2] = torch.arange(C)[C // 2:]
+        xi = x[:, order.to(x.device)].permute(0, 2, 3, 1).contiguous()
+        return self.forward_interleaved(xi).permute(0, 3, 1, 2)
+
+
+class P2P3Fusion(InferenceModule):
+    """conv1x1(p2) + nearest_up2(conv1x1(p3)) — the upsample+add is the first conv's epilogue."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.w: Dict[str, tuple] = {}
+
+    def import_weights(self, sd, device, prefix: str) -> None:
+        self.w = {"conv1": fold_conv(sd, prefix + "conv1", None, device),
+                  "conv2": fold_conv(sd, prefix + "conv2", None, device)}
+
+    def forward_nhwc(self, p2: torch.Tensor, p3: torch.Tensor) -> torch.Tensor:
+        t = K.conv2d_nhwc(p3, *self.w["conv2"])
+        return K.conv2d_nhwc(p2, *self.w["conv1"], residual=t, res_mode=2)
+
+    def forward(self, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+        from ..backbone.resnet_fpn import as_nhwc
+        return self.forward_nhwc(as_nhwc(x1), as_nhwc(x2)).permute(0, 3, 1, 2)

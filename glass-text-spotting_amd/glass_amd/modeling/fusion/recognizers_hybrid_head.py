@@ -1,0 +1,193 @@
+"""The GLASS ROI head (`MaskRotatedRecognizerHybridHead`), inference path, on HIP kernels.
+
+Mirrors reference glass/modeling/fusion/recognizers_hybrid_head.py: constructor wiring
+(`_init_box_head` :183-216, `_init_recognizer_head` :445-511), `forward` eval branch
+(:176-181), `_forward_box` (:291-339), `_forward_recognizer` (:513-569) and
+`forward_with_given_boxes` (:571-609; 3-argument form).  The mask branch is off at inference in
+every shipped config (`MASK_INFERENCE: false`) and is not built.
+
+Two surfaces:
+  * the reference's: `forward(images, features, proposals, targets=None) -> (list[Instances], {})`
+    with logical-NCHW feature tensors, so it drops into a detectron2-style meta-arch;
+  * `forward_batched(...)`: the device-resident path GlassRCNN uses — padded proposal slots in,
+    one host sync (the per-image detection counts), all RoIs of all images batched through the
+    recognition branch.  Per-image results are identical to calling the reference image by image.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ...utils.module import InferenceModule
+
+from ...ops import native as K
+from ...structures.core import ImageList, Instances, RotatedBoxes, ShapeSpec
+from ...utils.registry import ROI_HEADS_REGISTRY
+from ..backbone.resnet_fpn import as_nhwc
+from ..recognition.recognizer_head_v2 import build_recognizer_head
+from ..roi_heads.box_head import build_box_head
+from ..roi_heads.rotated_fast_rcnn import RotatedFastRCNNOutputLayers
+from .fusion_modules import P2P3Fusion, build_hybrid_feature_fusion
+from .local_feature_extraction import build_hybrid_feature_extractor
+
+
+def images_nhwc4(images: ImageList) -> torch.Tensor:
+    """NHWC4 batch behind an ImageList (ours carry it; a foreign one is converted once)."""
+    t = getattr(images, "nhwc4", None)
+    if t is not None:
+        return t
+    x = images.tensor.permute(0, 2, 3, 1)
+    if x.shape[-1] == 3:
+        x = torch.nn.functional.pad(x, (0, 1))
+    return x.contiguous()
+
+
+@ROI_HEADS_REGISTRY.register()
+class MaskRotatedRecognizerHybridHead(InferenceModule):
+    def __init__(self, cfg, input_shape: Dict[str, ShapeSpec]):
+        super().__init__()
+        # ---- box branch (:183-216)
+        self.box_in_features = list(cfg.MODEL.ROI_HEADS.IN_FEATURES)
+        self.box_pooler_resolution = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        self.box_pooler_scales = tuple(1.0 / input_shape[k].stride for k in self.box_in_features)
+        self.box_sampling_ratio = cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO
+        assert cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE in ["ROIAlignRotated"], cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE
+        in_channels = [input_shape[f].channels for f in self.box_in_features][0]
+        r = self.box_pooler_resolution
+        self.box_head = build_box_head(cfg, ShapeSpec(channels=in_channels, height=r, width=r))
+        self.box_predictor = RotatedFastRCNNOutputLayers(cfg, self.box_head.output_shape)
+        # ---- recognizer branch (:445-511)
+        self.recognizer_on = bool(cfg.MODEL.RECOGNIZER_ON)
+        rc = cfg.MODEL.ROI_RECOGNIZER_HEAD
+        self.recognizer_in_features = list(rc.IN_FEATURES)
+        assert rc.POOLER_TYPE in ["ROIAlignRotated"], rc.POOLER_TYPE
+        assert not rc.RECOGNIZER_HEAD.POOLER_PAD.NAME, "POOLER_PAD is not built (empty in all reference configs)"
+        assert len(self.recognizer_in_features) == 2, "recognizer expects [p2, p3] (all reference configs)"
+        self.rec_ph, self.rec_pw = rc.POOLER_RESOLUTION_HEIGHT, rc.POOLER_RESOLUTION_WIDTH
+        self.rec_scale = 1.0 / input_shape[self.recognizer_in_features[0]].stride
+        self.rec_sampling_ratio = rc.POOLER_SAMPLING_RATIO
+        rin = input_shape[self.recognizer_in_features[0]].channels
+        self.recognizer_feature_fusion = P2P3Fusion(rin)
+        shape = ShapeSpec(channels=rin, width=self.rec_pw, height=self.rec_ph)
+        self.img_pooler_size = (self.rec_ph * 16, self.rec_pw * 4)
+        self.img_sampling_ratio = cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO
+        self.hybrid_net = build_hybrid_feature_extractor(cfg, shape)
+        self.fusion_net = build_hybrid_feature_fusion(cfg, shape)
+        self.recognizer_head = build_recognizer_head(cfg, shape)
+        self.mask_inference = bool(cfg.MODEL.ROI_MASK_HEAD.MASK_INFERENCE)
+        if self.mask_inference:
+            raise NotImplementedError("rotated mask branch at inference is not built (SURVEY.md §8 f2)")
+        self.local_ch = cfg.MODEL.LOCAL_FEATURE_EXTRACTOR.NUM_FEATURES
+
+    def import_weights(self, sd, device, prefix: str = "roi_heads.") -> None:
+        self.box_head.import_weights(sd, device, prefix + "box_head.")
+        self.box_predictor.import_weights(sd, device, prefix + "box_predictor.")
+        self.recognizer_feature_fusion.import_weights(sd, device, prefix + "recognizer_feature_fusion.")
+        self.hybrid_net.import_weights(sd, device, prefix + "hybrid_net.")
+        self.fusion_net.import_weights(sd, device, prefix + "fusion_net.")
+        self.recognizer_head.import_weights(sd, device, prefix + "recognizer_head.")
+
+    # ================================================================== device-resident path
+    def box_branch_batched(self, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor, prop_counts: torch.Tensor,
+                           image_hw_dev: torch.Tensor):
+        """feats: NHWC level tensors by name; prop_boxes [N,P,5] (padded), prop_counts int32 [N]."""
+        N, P, _ = prop_boxes.shape
+        device = prop_boxes.device
+        bidx = torch.arange(N, dtype=torch.int32, device=device).repeat_interleave(P)
+        fl = [feats[f] for f in self.box_in_features]
+        r = self.box_pooler_resolution
+        pooled = K.roi_align_rotated(fl, self.box_pooler_scales, prop_boxes.view(-1, 5), bidx, (r, r), self.box_sampling_ratio)
+        x = self.box_head.forward_nhwc(pooled)
+        preds = self.box_predictor(x)
+        return self.box_predictor.inference_batched(preds, prop_boxes, prop_counts, image_hw_dev)
+
+    def recognizer_branch_batched(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], boxes: torch.Tensor,
+                                  roi_image: torch.Tensor, num_images: int, return_intermediates: bool = False):
+        """boxes [R,5], roi_image int32 [R] -> pred_text_prob [R,26,97] (R > 0)."""
+        R = boxes.shape[0]
+        g = self.recognizer_feature_fusion.forward_nhwc(feats[self.recognizer_in_features[0]],
+                                                        feats[self.recognizer_in_features[1]])
+        C = g.shape[-1]
+        # channel-interleaved cat(local, global): local -> even channels, global -> odd channels
+        xcat = torch.empty((R, self.rec_ph, self.rec_pw, self.local_ch + C), dtype=torch.float32, device=boxes.device)
+        K.roi_align_rotated([g], [self.rec_scale], boxes, roi_image, (self.rec_ph, self.rec_pw), self.rec_sampling_ratio,
+                            out=xcat, out_coff=1, out_cstride=2)
+        crops = K.roi_align_rotated([img_nhwc4], [1.0], boxes, roi_image, self.img_pooler_size, self.img_sampling_ratio,
+                                    channels=4)
+        self.hybrid_net.forward_nhwc(crops, out=xcat, out_coff=0, out_cstride=2)
+        inter = {"xcat": xcat.clone(), "crops": crops} if return_intermediates else None
+        fused = self.fusion_net.forward_interleaved(xcat)
+        probs = self.recognizer_head.forward_nhwc(fused, roi_image, num_images)
+        if return_intermediates:
+            inter["fused"] = fused
+            return probs, inter
+        return probs
+
+    def forward_batched(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor,
+                        prop_counts: torch.Tensor, image_sizes: List[Tuple[int, int]],
+                        override_boxes: Optional[List[torch.Tensor]] = None) -> List[Instances]:
+        device = prop_boxes.device
+        hw = torch.tensor(image_sizes, dtype=torch.int32, device=device)
+        ob, os_, oi, orient2, oc = self.box_branch_batched(feats, prop_boxes, prop_counts, hw)
+        # the one host sync of the step: per-image detection counts
+        results, _ = self.box_predictor.to_instances(ob, os_, oi, orient2, oc, image_sizes)
+        if override_boxes is not None:
+            # synthetic-workload hook (bench / teacher-forced parity): recognise these boxes instead
+            results = []
+            for b, image_size in zip(override_boxes, image_sizes):
+                r = Instances(image_size)
+                r.pred_boxes = RotatedBoxes(b.to(device).float().contiguous())
+                r.scores = torch.ones((len(b),), dtype=torch.float32, device=device)
+                r.pred_classes = torch.zeros((len(b),), dtype=torch.int64, device=device)
+                r.orientations = torch.zeros((len(b), 2), dtype=torch.float32, device=device)
+                results.append(r)
+        return self._recognize_into(img_nhwc4, feats, results)
+
+    def _recognize_into(self, img_nhwc4, feats, results: List[Instances]) -> List[Instances]:
+        if not self.recognizer_on:
+            return results
+        counts = [len(r) for r in results]
+        R = sum(counts)
+        if R == 0:
+            return results        # reference: recognizer_head returns the instances untouched (recognizer_head_v2.py:151)
+        device = img_nhwc4.device
+        boxes = torch.cat([r.pred_boxes.tensor for r in results], 0).contiguous()
+        roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
+        probs = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts))
+        for p, r in zip(probs.split(counts, dim=0), results):
+            r.pred_text_prob = p
+        return results
+
+    # ================================================================== reference surface
+    def _nhwc_feats(self, features: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        return {k: as_nhwc(v) for k, v in features.items()}
+
+    def forward(self, images: ImageList, features: Dict[str, torch.Tensor], proposals: List[Instances], targets=None):
+        assert not self.training and targets is None, "inference only (training is out of scope)"
+        pred_instances = self._forward_box(features, proposals)
+        pred_instances = self.forward_with_given_boxes(images, features, pred_instances)
+        return pred_instances, {}
+
+    def _forward_box(self, features: Dict[str, torch.Tensor], proposals: List[Instances]) -> List[Instances]:
+        feats = self._nhwc_feats({f: features[f] for f in self.box_in_features})
+        device = feats[self.box_in_features[0]].device
+        counts = [len(p) for p in proposals]
+        N, P = len(proposals), max(counts + [1])
+        pb = torch.zeros((N, P, 5), dtype=torch.float32, device=device)
+        for n, p in enumerate(proposals):
+            pb[n, : counts[n]] = p.proposal_boxes.tensor
+        hw = torch.tensor([p.image_size for p in proposals], dtype=torch.int32, device=device)
+        cnt = torch.tensor(counts, dtype=torch.int32, device=device)
+        ob, os_, oi, orient2, oc = self.box_branch_batched(feats, pb, cnt, hw)
+        results, _ = self.box_predictor.to_instances(ob, os_, oi, orient2, oc, [p.image_size for p in proposals])
+        return results
+
+    def _forward_recognizer(self, images: ImageList, features: Dict[str, torch.Tensor], instances: List[Instances]):
+        feats = self._nhwc_feats({f: features[f] for f in self.recognizer_in_features})
+        return self._recognize_into(images_nhwc4(images), feats, instances)
+
+    def forward_with_given_boxes(self, images: ImageList, features: Dict[str, torch.Tensor], instances: List[Instances]):
+        assert not self.training
+        assert instances[0].has("pred_boxes") and instances[0].has("pred_classes")
+        return self._forward_recognizer(images, features, instances)

@@ -1,0 +1,143 @@
+"""Meta-architectures: `GeneralizedRCNN` (d2 flow) and `GlassRCNN` on the HIP pipeline.
+
+Mirrors reference glass/modeling/meta_arch/glass_rcnn.py:13-128 (`GlassRCNN.from_config` :36-55,
+`inference` :57-101, `_postprocess` :103-128) and, for `glass_pretrain.yaml` which selects d2's
+stock `GeneralizedRCNN` (configs/glass_pretrain.yaml:40), the same flow with d2's
+`detector_postprocess` [d2-recall].  Call convention is the reference's:
+`model(batched_inputs: list[{'image': Tensor[3,H,W] float 0..255, 'height', 'width'}])
+ -> list[{'instances': Instances}]`.
+
+Batches: the reference effectively runs one image per call; a batch here gives,
+per image, exactly what the reference gives when run image by image.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from ...utils.module import InferenceModule
+
+from ...checkpoint import load_checkpoint_file
+from ...ops import native as K
+from ...postprocess import build_post_processor
+from ...postprocess.post_processor_academic import detector_postprocess
+from ...structures.core import ImageList, Instances
+from ...utils.registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY
+from ..backbone import resnet_fpn as _resnet_fpn  # noqa: F401  (registers the backbone builder)
+from ..backbone.resnet_fpn import as_nchw_view
+from ..fusion import recognizers_hybrid_head as _hh  # noqa: F401  (registers the ROI head)
+from ..proposal_generator import rotated_rpn as _rrpn  # noqa: F401  (registers RotatedRPN)
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN(InferenceModule):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self._device = torch.device(cfg.MODEL.DEVICE)
+        self.backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, None)
+        shapes = self.backbone.output_shape()
+        self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, shapes)
+        self.roi_heads = ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, shapes)
+        self.pixel_mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+        self.input_format = cfg.INPUT.FORMAT
+        self._loaded = False
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """d2-keyed state dict (what DetectionCheckpointer hands over) -> folded, re-laid device
+        weights.  `roi_heads.mask_head.*` keys are ignored (mask branch off at inference)."""
+        dev = self._device
+        self.backbone.import_weights(state_dict, dev, "backbone.")
+        self.proposal_generator.import_weights(state_dict, dev, "proposal_generator.")
+        self.roi_heads.import_weights(state_dict, dev, "roi_heads.")
+        self._loaded = True
+        return self
+
+    def load_checkpoint(self, path: str):
+        return self.load_state_dict(load_checkpoint_file(path))
+
+    # ------------------------------------------------------------------ pipeline
+    def preprocess_image(self, batched_inputs: List[Dict]) -> ImageList:
+        """normalise + zero-pad to a multiple of 32 into one NHWC4 batch (glass_rcnn.py:82)."""
+        imgs = [x["image"] for x in batched_inputs]
+        sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in imgs]
+        Hp, Wp = ImageList.padded_shape(sizes, self.backbone.size_divisibility)
+        batch = torch.empty((len(imgs), Hp, Wp, 4), dtype=torch.float32, device=self._device)
+        for n, im in enumerate(imgs):
+            im = im.to(self._device)
+            if im.dtype != torch.float32:
+                im = im.float()
+            K.preprocess_image(im.contiguous(), self.pixel_mean, self.pixel_std, batch, n)
+        il = ImageList(as_nchw_view(batch)[:, :3], sizes)
+        il.nhwc4 = batch
+        return il
+
+    def forward(self, batched_inputs: List[Dict], **kw):
+        return self.inference(batched_inputs, **kw)
+
+    def inference(self, batched_inputs: List[Dict], detected_instances: Optional[List[Instances]] = None,
+                  do_postprocess: bool = True, override_boxes: Optional[List[torch.Tensor]] = None):
+        assert not self.training
+        if not self._loaded:
+            raise RuntimeError("no weights loaded: call load_state_dict()/load_checkpoint() first")
+        with torch.no_grad():
+            images = self.preprocess_image(batched_inputs)
+            feats = self.backbone.forward_nhwc(images.nhwc4)
+            if detected_instances is None:
+                hw = torch.tensor(images.image_sizes, dtype=torch.int32, device=self._device)
+                rpn_in = [feats[f] for f in self.proposal_generator.in_features]
+                pboxes, _plogits, pcounts = self.proposal_generator.forward_batched(rpn_in, hw)
+                results = self.roi_heads.forward_batched(images.nhwc4, feats, pboxes, pcounts, images.image_sizes,
+                                                         override_boxes=override_boxes)
+            else:
+                detected_instances = [x.to(self._device) for x in detected_instances]
+                results = self.roi_heads._recognize_into(images.nhwc4, feats, detected_instances)
+            if do_postprocess:
+                return self._postprocess(results, batched_inputs, images.image_sizes)
+            return results
+
+    def _postprocess(self, instances, batched_inputs, image_sizes):
+        out = []
+        for r, inp, image_size in zip(instances, batched_inputs, image_sizes):
+            height = inp.get("height", image_size[0])
+            width = inp.get("width", image_size[1])
+            out.append({"instances": detector_postprocess(r, height, width)})
+        return out
+
+
+@META_ARCH_REGISTRY.register()
+class GlassRCNN(GeneralizedRCNN):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        pp = cfg.POST_PROCESSING
+        self.post_processor = build_post_processor(cfg)
+        self.inflate_ratio = pp.INFLATE_RATIO if hasattr(pp, "INFLATE_RATIO") else None
+        self.transcript_filtering = pp.TRANSCRIPT_FILTERING if hasattr(pp, "TRANSCRIPT_FILTERING") else None
+        self.filter_small_boxes = pp.MIN_BOX_DIMENSION if hasattr(pp, "MIN_BOX_DIMENSION") else None
+        self.drop_overlapping_boxes = pp.DROP_OVERLAPPING if hasattr(pp, "DROP_OVERLAPPING") else None
+        self.ioa_threshold = pp.IOA_THRESHOLD if hasattr(pp, "IOA_THRESHOLD") else None
+        self.valid_score = cfg.INFERENCE_TH_TEST if hasattr(cfg, "INFERENCE_TH_TEST") else 0
+        if self.inflate_ratio or self.drop_overlapping_boxes:
+            raise NotImplementedError("INFLATE_RATIO / DROP_OVERLAPPING (eval-CLI only keys) are not built")
+
+    def _postprocess(self, instances, batched_inputs, image_sizes):
+        out = []
+        for r, inp, image_size in zip(instances, batched_inputs, image_sizes):
+            height = inp.get("height", image_size[0])
+            width = inp.get("width", image_size[1])
+            if self.filter_small_boxes:
+                r = self.post_processor.filter_small_boxes(r)
+            out.append({"instances": detector_postprocess(r, height, width)})
+        return out
+
+
+def build_model(cfg) -> torch.nn.Module:
+    """Work-alike of `detectron2.modeling.build_model`: META_ARCH_REGISTRY lookup by cfg name."""
+    return META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)

@@ -1,0 +1,62 @@
+"""Recognizer head (`RecognizerRCNNHeadV3`): CNN -> BiLSTM encoder -> attention decoder.
+
+Mirrors reference glass/modeling/recognition/recognizer_head_v2.py:291-345 and the eval branch
+of `BaseRecognizerRCNNHead.forward` (:150-163): empty input returns the instances untouched,
+otherwise `pred_text_prob` [Ri,26,97] is attached per image.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from ...utils.module import InferenceModule
+
+from ...structures.core import Instances
+from ...utils.registry import Registry
+from .recognizer_backbone import build_recognizer_backbonev2
+from .recognizer_decoder import build_recognizer_decoderv2
+from .recognizer_encoder import build_recognizer_encoderv2
+from .text_encoder import TextEncoder
+
+ROI_RECOGNIZER_HEAD_REGISTRY = Registry("ROI_RECOGNIZER_HEAD")
+
+
+@ROI_RECOGNIZER_HEAD_REGISTRY.register()
+class RecognizerRCNNHeadV3(InferenceModule):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        self.backbone = build_recognizer_backbonev2(cfg, input_shape)
+        self.encoder = build_recognizer_encoderv2(cfg, input_shape)
+        self.decoder = build_recognizer_decoderv2(cfg, input_shape)
+        self.max_word_length = cfg.MODEL.ROI_RECOGNIZER_HEAD.MAX_WORD_LENGTH
+        self.class_ind = cfg.MODEL.ROI_RECOGNIZER_HEAD.CLASS_IND
+        self.text_encoder = TextEncoder(cfg)
+
+    def import_weights(self, sd, device, prefix: str) -> None:
+        self.backbone.import_weights(sd, device, prefix + "backbone.")
+        self.encoder.import_weights(sd, device, prefix + "encoder.")
+        self.decoder.import_weights(sd, device, prefix + "decoder.")
+
+    def forward_nhwc(self, x: torch.Tensor, roi_image: torch.Tensor, num_images: int) -> torch.Tensor:
+        """x [R,8,32,256] fused features -> probabilities [R,26,97]."""
+        f = self.backbone.forward_nhwc(x)
+        enc = self.encoder.forward_nhwc(f)
+        return self.decoder(enc, roi_image=roi_image, num_images=num_images)
+
+    def forward(self, x: torch.Tensor, instances: List[Instances]):
+        assert not self.training, "inference only"
+        if x.shape[0] == 0:
+            return instances
+        from ..backbone.resnet_fpn import as_nhwc
+        counts = [len(i) for i in instances]
+        roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32),
+                                            torch.tensor(counts)).to(x.device)
+        preds = self.forward_nhwc(as_nhwc(x), roi_image, len(counts))
+        for p, inst in zip(preds.split(counts, dim=0), instances):
+            inst.pred_text_prob = p
+        return instances
+
+
+def build_recognizer_head(cfg, input_shape):
+    return ROI_RECOGNIZER_HEAD_REGISTRY.get(cfg.MODEL.ROI_RECOGNIZER_HEAD.NAME)(cfg, input_shape)

@@ -162,3 +162,133 @@ def roi_align_rotated(feats: List[torch.Tensor], scales: Sequence[float], boxes:
         check(lib().glass_roi_align_rotated(ctypes.byref(d), c_void_p(_dev(boxes)), c_void_p(_dev(batch_idx)), R,
                                             c_void_p(_dev(out)), c_void_p(stream_handle())), "glass_roi_align_rotated")
     return out
+
+
+# --------------------------------------------------------------------------- proposals
+def _i32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        raise GlassLibraryError(f"{name} must be contiguous int32")
+    return t
+
+
+def rpn_level_topk_decode(logits: torch.Tensor, ldl: int, deltas: torch.Tensor, ldd: int, N: int, H: int, W: int, A: int,
+                          stride: int, anchor_offset: float, cell_anchors: torch.Tensor, weights: Sequence[float], topk: int,
+                          level_id: int, slot_off: int, out_boxes: torch.Tensor, out_scores: torch.Tensor,
+                          out_level: torch.Tensor) -> None:
+    """`logits`/`deltas` may be channel slices of one head tensor (pass the sliced view's
+    data pointer through `.data_ptr()` of a narrow()ed tensor; ld* is the pixel stride)."""
+    w = (c_float * 5)(*[float(v) for v in weights])
+    S = out_boxes.shape[1]
+    check(lib().glass_rpn_level_topk_decode(
+        c_void_p(_dev(logits)), int(ldl), c_void_p(_dev(deltas)), int(ldd), N, H, W, A, int(stride), c_float(anchor_offset),
+        c_void_p(_dev(cell_anchors)), w, int(topk), int(level_id), int(slot_off), int(S), c_void_p(_dev(out_boxes)),
+        c_void_p(_dev(out_scores)), c_void_p(_dev(out_level)), c_void_p(stream_handle())), "glass_rpn_level_topk_decode")
+
+
+NMS_CLIP, NMS_DROP_EMPTY = 1, 2
+
+
+def rotated_nms_select(boxes: torch.Tensor, scores: torch.Tensor, cat: Optional[torch.Tensor],
+                       valid_count: Optional[torch.Tensor], image_hw: torch.Tensor, score_thresh: float, nms_thresh: float,
+                       post_topk: int, flags: int):
+    """boxes [N,S,5], scores [N,S] -> (out_boxes [N,K,5], out_scores [N,K], out_index [N,K], out_count [N])."""
+    _f32c(boxes, "boxes"); _f32c(scores, "scores"); _i32(image_hw, "image_hw")
+    N, S = scores.shape
+    dev = boxes.device
+    ob = torch.zeros((N, post_topk, 5), dtype=torch.float32, device=dev)
+    os_ = torch.zeros((N, post_topk), dtype=torch.float32, device=dev)
+    oi = torch.zeros((N, post_topk), dtype=torch.int32, device=dev)
+    oc = torch.zeros((N,), dtype=torch.int32, device=dev)
+    check(lib().glass_rotated_nms_select(
+        c_void_p(_dev(boxes)), c_void_p(_dev(scores)), c_void_p(_dev(_i32(cat, "cat")) if cat is not None else None),
+        c_void_p(_dev(_i32(valid_count, "valid_count")) if valid_count is not None else None), N, S,
+        c_void_p(_dev(image_hw)), c_float(score_thresh), c_float(nms_thresh), int(post_topk), int(flags),
+        c_void_p(_dev(ob)), c_void_p(_dev(os_)), c_void_p(_dev(oi)), c_void_p(_dev(oc)), c_void_p(stream_handle())),
+        "glass_rotated_nms_select")
+    return ob, os_, oi, oc
+
+
+def pairwise_iou_rotated(b1: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    _f32c(b1, "boxes1"); _f32c(b2, "boxes2")
+    out = torch.zeros((b1.shape[0], b2.shape[0]), dtype=torch.float32, device=b1.device)
+    if out.numel():
+        check(lib().glass_pairwise_iou_rotated(c_void_p(_dev(b1)), b1.shape[0], c_void_p(_dev(b2)), b2.shape[0],
+                                               c_void_p(_dev(out)), c_void_p(stream_handle())), "glass_pairwise_iou_rotated")
+    return out
+
+
+def box_decode(cls_logits: torch.Tensor, deltas: torch.Tensor, orient_logits: torch.Tensor, proposals: torch.Tensor,
+               weights: Sequence[float]):
+    R = proposals.shape[0]
+    dev = proposals.device
+    ob = torch.empty((R, 5), dtype=torch.float32, device=dev)
+    fg = torch.empty((R,), dtype=torch.float32, device=dev)
+    orr = torch.empty((R, 2), dtype=torch.float32, device=dev)
+    w = (c_float * 5)(*[float(v) for v in weights])
+    if R:
+        for t, nm in ((cls_logits, "cls"), (deltas, "deltas"), (orient_logits, "orient"), (proposals, "proposals")):
+            _f32c(t, nm)
+        check(lib().glass_box_decode(c_void_p(_dev(cls_logits)), c_void_p(_dev(deltas)), c_void_p(_dev(orient_logits)),
+                                     c_void_p(_dev(proposals)), R, w, c_void_p(_dev(ob)), c_void_p(_dev(fg)),
+                                     c_void_p(_dev(orr)), c_void_p(stream_handle())), "glass_box_decode")
+    return ob, fg, orr
+
+
+# --------------------------------------------------------------------------- recognition
+def pack_kblocked(w: torch.Tensor) -> torch.Tensor:
+    """W [rows, K] -> packed [K/4, rows, 4] (see include/glass_hip.h); load-time plumbing."""
+    rows, K = w.shape
+    assert K % 4 == 0
+    return w.reshape(rows, K // 4, 4).permute(1, 0, 2).contiguous()
+
+
+def gc_attention_inplace(x: torch.Tensor, heads: int, w_mask, b_mask, w1, b1, ln_g, ln_b, w2, b2) -> torch.Tensor:
+    """x [R,H,W,C] interleaved cat(local,global); modified in place."""
+    _f32c(x, "x")
+    R, H, W, C = x.shape
+    P = w1.shape[0]
+    if R:
+        check(lib().glass_gc_attention_inplace(
+            c_void_p(_dev(x)), R, H * W, C, int(heads), P, *[c_void_p(_dev(_f32c(t, "w"))) for t in
+                                                           (w_mask, b_mask, w1, b1, ln_g, ln_b, w2, b2)],
+            c_void_p(stream_handle())), "glass_gc_attention_inplace")
+    return x
+
+
+def mean_over_h(x: torch.Tensor) -> torch.Tensor:
+    _f32c(x, "x")
+    R, H, W, C = x.shape
+    y = torch.empty((R, W, C), dtype=torch.float32, device=x.device)
+    check(lib().glass_mean_over_h(c_void_p(_dev(x)), c_void_p(_dev(y)), R, H, W, C, c_void_p(stream_handle())),
+          "glass_mean_over_h")
+    return y
+
+
+def bilstm_recurrence(xg: torch.Tensor, w_hh_packed: torch.Tensor, hidden: int) -> torch.Tensor:
+    """xg [R,T,2,4*Hd] -> out [R,T,2*Hd]."""
+    _f32c(xg, "xg"); _f32c(w_hh_packed, "w_hh_packed")
+    R, T = xg.shape[0], xg.shape[1]
+    out = torch.empty((R, T, 2 * hidden), dtype=torch.float32, device=xg.device)
+    check(lib().glass_bilstm_recurrence(c_void_p(_dev(xg)), c_void_p(_dev(w_hh_packed)), c_void_p(_dev(out)), R, T, hidden,
+                                        c_void_p(stream_handle())), "glass_bilstm_recurrence")
+    return out
+
+
+def attention_decode(x: torch.Tensor, xproj: torch.Tensor, weights: dict, roi_image: torch.Tensor, num_images: int,
+                     num_classes: int, max_len: int, eos: int) -> torch.Tensor:
+    """x, xproj [R,T,D]; weights: dict of packed device tensors + 'temperature' float."""
+    _f32c(x, "x"); _f32c(xproj, "xproj"); _i32(roi_image, "roi_image")
+    R, T, D = x.shape
+    out = torch.empty((R, max_len, num_classes), dtype=torch.float32, device=x.device)
+    if R == 0:
+        return out
+    pred = torch.empty((R, max_len), dtype=torch.int32, device=x.device)
+    w = DecoderWeights()
+    for n in ("sW", "sB", "wW", "wB", "emb", "w_ih", "w_hh", "b_ih", "b_hh", "fcW", "fcB"):
+        setattr(w, n, _dev(_f32c(weights[n], n)))
+    w.temperature = float(weights["temperature"])
+    check(lib().glass_attention_decode(c_void_p(_dev(x)), c_void_p(_dev(xproj)), ctypes.byref(w), c_void_p(_dev(roi_image)),
+                                       R, int(num_images), T, D, int(num_classes), int(max_len), int(eos),
+                                       c_void_p(_dev(out)), c_void_p(_dev(pred)), c_void_p(stream_handle())),
+          "glass_attention_decode")
+    return out

@@ -1,0 +1,66 @@
+"""`PostProcessorAcademic` + `detector_postprocess` + `get_instances_text`.
+
+Behavioural mirror of reference glass/postprocess/post_processor_academic.py:19-35 (text-score
+filter after the rotated-box post-process), :118-178 (`detector_postprocess`: scale, clip, drop
+empty; the mask paste branch is out of scope) and glass/evaluation/text_evaluator.py:323-348
+(`get_instances_text`: argmax -> TextEncoder.decode_prod_v2 -> strip one leading/trailing
+special character).
+"""
+from __future__ import annotations
+
+import torch
+
+from ..modeling.recognition.text_encoder import TextEncoder
+from ..structures.core import Instances
+from .post_processor_rotated_boxes import POST_PROCESSOR_REGISTRY, PostProcessorRotatedBoxes
+
+_SPECIAL = str("'!?.:,*+\"()·[]/\\#$%;<=>@^_`{|}~")
+
+
+def get_instances_text(text_probs, text_encoder, onlyRemoveFirstLastCharacter=True):
+    if len(text_probs):
+        text_probs = text_probs.detach().cpu()
+        pred_probs, pred_idx = text_probs.max(dim=2)
+        text_probs = text_probs.numpy()
+        objs = text_encoder.decode_prod_v2(pred_probs=pred_probs.numpy(), pred_indices=pred_idx.numpy())
+        pred_text = [o["text"] for o in objs]
+        pred_scores = [o["score"] for o in objs]
+        if onlyRemoveFirstLastCharacter:
+            for i in range(len(pred_text)):
+                if len(pred_text[i]) > 0 and _SPECIAL.find(pred_text[i][0]) > -1:
+                    pred_text[i] = pred_text[i][1:]
+                if len(pred_text[i]) > 0 and _SPECIAL.find(pred_text[i][-1]) > -1:
+                    pred_text[i] = pred_text[i][:-1]
+    else:
+        pred_text, pred_scores, text_probs = [], [], []
+    return pred_text, pred_scores, text_probs
+
+
+@POST_PROCESSOR_REGISTRY.register()
+class PostProcessorAcademic(PostProcessorRotatedBoxes):
+    def __init__(self, cfg, *args, **kwargs):
+        super().__init__(cfg, *args, **kwargs)
+        self.text_threshold = cfg.POST_PROCESSING.TEXT_THRESHOLD
+        self.text_encoder = TextEncoder(cfg)
+
+    def __call__(self, preds, scale_ratio=1, **kwargs):
+        preds = super().__call__(preds)
+        texts, text_scores, _ = get_instances_text(preds.pred_text_prob, self.text_encoder)
+        keep = torch.tensor(text_scores) >= self.text_threshold
+        return preds[keep.to(preds.pred_boxes.device) if len(text_scores) else torch.zeros((0,), dtype=torch.bool)]
+
+
+def detector_postprocess(results: Instances, output_height, output_width, mask_threshold=0.5) -> Instances:
+    ow = output_width.float() if isinstance(output_width, torch.Tensor) else output_width
+    oh = output_height.float() if isinstance(output_height, torch.Tensor) else output_height
+    scale_x, scale_y = ow / results.image_size[1], oh / results.image_size[0]
+    results = Instances((output_height, output_width), **results.get_fields())
+    if results.has("pred_boxes"):
+        output_boxes = results.pred_boxes
+    elif results.has("proposal_boxes"):
+        output_boxes = results.proposal_boxes
+    else:
+        return results
+    output_boxes.scale(scale_x, scale_y)
+    output_boxes.clip(results.image_size)
+    return results[output_boxes.nonempty()]

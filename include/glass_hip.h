@@ -106,28 +106,27 @@ int glass_roi_align_rotated(const glass_roialign_desc* d, const float* boxes, co
  * selected, their anchors generated analytically, deltas applied
  * (Box2BoxTransformRotated), and written to out_boxes[n][slot_off + i] / out_scores /
  * out_level.  logits: [N,H,W,A] (pixel stride ldl), deltas: [N,H,W,A*5] (pixel stride ldd).
- * cell_anchors: [A,5] host-computed (w,h,angle used).  workspace: >= glass_rpn_topk_workspace(). */
-int64_t glass_rpn_topk_workspace(int N, int HWA);
+ * cell_anchors_dev: [A,5] on device ((.,.,w,h,angle) per anchor).  topk <= 2048.                 */
 int glass_rpn_level_topk_decode(const float* logits, int ldl, const float* deltas, int ldd, int N, int H, int W, int A,
                                 int stride, float anchor_offset, const float* cell_anchors_dev, const float* weights5_host,
                                 int topk, int level_id, int slot_off, int slots_per_image, float* out_boxes,
-                                float* out_scores, int* out_level, void* workspace, int64_t workspace_bytes,
-                                glass_stream_t stream);
+                                float* out_scores, int* out_level, glass_stream_t stream);
 
-/* Per image: drop non-finite, clip (|angle|<=1 deg only), drop empty, class/level-offset
- * greedy rotated NMS (iou >= thr suppresses; CPU semantics of d2 nms_rotated), keep the
- * first `post_topk` in descending score order.  Used for RPN (thr 0.7, post 100) and for
- * the box head (glass/modeling/roi_heads/rotated_fast_rcnn.py:88-148: score filter,
- * thr 0.35, top 100).  boxes [N,S,5], scores [N,S], cat [N,S] (level / class id),
- * valid_count [N] (slots used per image; NULL = S).  image_hw [N,2] ints (h,w) on device.
- * Inputs must already be sorted by descending score within each image unless
- * `needs_sort` != 0.  Outputs: out_boxes [N,post_topk,5], out_scores [N,post_topk],
- * out_index [N,post_topk] (slot index into the input), out_count [N].                    */
-int64_t glass_nms_workspace(int N, int S);
+/* Per image: drop non-finite rows, drop rows with score <= score_thresh, clip (|angle| <= 1
+ * deg only; flag GLASS_NMS_CLIP), drop empty boxes (flag GLASS_NMS_DROP_EMPTY), sort by
+ * descending score (stable), class/level-offset greedy rotated NMS (iou >= thr suppresses:
+ * CPU semantics of d2 nms_rotated), keep the first `post_topk`.
+ * Used for RPN (thr 0.7, post 100, CLIP|DROP_EMPTY; d2 find_top_rrpn_proposals) and for the
+ * box head (glass/modeling/roi_heads/rotated_fast_rcnn.py:88-148: CLIP, score > 0.05,
+ * thr 0.35, top 100).  boxes [N,S,5], scores [N,S], cat [N,S] (level / class id; NULL = 0),
+ * valid_count [N] device ints (slots used per image; NULL = S), image_hw [N,2] device ints
+ * (h,w).  S <= 8192.  Outputs: out_boxes [N,post_topk,5] (clipped), out_scores
+ * [N,post_topk], out_index [N,post_topk] (slot index into the input), out_count [N].     */
+#define GLASS_NMS_CLIP 1
+#define GLASS_NMS_DROP_EMPTY 2
 int glass_rotated_nms_select(const float* boxes, const float* scores, const int* cat, const int* valid_count, int N, int S,
-                             const int* image_hw, float score_thresh, float nms_thresh, int post_topk, int needs_sort,
-                             int do_clip, float* out_boxes, float* out_scores, int* out_index, int* out_count,
-                             void* workspace, int64_t workspace_bytes, glass_stream_t stream);
+                             const int* image_hw, float score_thresh, float nms_thresh, int post_topk, int flags,
+                             float* out_boxes, float* out_scores, int* out_index, int* out_count, glass_stream_t stream);
 
 /* Box-head prediction decode (glass/modeling/roi_heads/rotated_fast_rcnn.py:335-342,
  * 480-491): softmax over (K+1=2) class logits, apply_deltas with weights, orientation
@@ -136,44 +135,60 @@ int glass_box_decode(const float* cls_logits, const float* deltas, const float* 
                      int R, const float* weights5_host, float* out_boxes, float* out_fg_prob, float* out_orient2,
                      glass_stream_t stream);
 
+/* pairwise rotated IoU matrix out[n1][n2] (d2 pairwise_iou_rotated; glass/structures/boxes.py:33,
+ * used by the post-processor's pairwise_ioa_rotated).                                     */
+int glass_pairwise_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2, float* out,
+                               glass_stream_t stream);
+
 /* ------------------------------------------------------------------ fusion attention
  * MultiAspectGCAttention minus its out-conv (glass/modeling/fusion/fusion_modules.py:
  * 91-154): x is the channel-INTERLEAVED cat(local,global) [R,HW,C] (C=512, channel 2i =
  * local i, 2i+1 = global i, i.e. already x[:, order]); per head softmax(conv_mask) pooling,
  * channel_add MLP (conv1x1 -> LayerNorm -> ReLU -> conv1x1) and the broadcast add are
  * applied IN PLACE on x.  w_mask [C/heads], b_mask [1], w1 [P][C], b1 [P], ln_g/ln_b [P],
- * w2 [C][P], b2 [C].                                                                     */
+ * w2 [C][P], b2 [C].  Requires C == 512, heads == 8, P == 256, HW == 256 (the GLASS shapes). */
 int glass_gc_attention_inplace(float* x, int R, int HW, int C, int heads, int P, const float* w_mask, const float* b_mask,
                                const float* w1, const float* b1, const float* ln_g, const float* ln_b, const float* w2,
-                               const float* b2, float* scratch /* R*(C+P) floats */, glass_stream_t stream);
+                               const float* b2, glass_stream_t stream);
 
 /* mean over H of an NHWC map: [R,H,W,C] -> [R,W,C]
  * (BiLSTMBlockV2.forward, glass/modeling/recognition/recognizer_encoder.py:119).          */
 int glass_mean_over_h(const float* x, float* y, int R, int H, int W, int C, glass_stream_t stream);
 
+/* "k-blocked" weight packing used by the recurrent kernels so that a thread owning output row j
+ * streams 16-byte pieces that are contiguous across neighbouring threads:
+ *   packed[k/4][j][k%4] = W[j][k]   for W [rows][K], K % 4 == 0.
+ * The host packs once at checkpoint load (any tensor library can do it:
+ *   W.view(rows, K/4, 4).permute(1, 0, 2).contiguous()).                                   */
+
 /* ------------------------------------------------------------------ recurrent encoder
  * One bidirectional LSTM layer's recurrence (nn.LSTM gate order i,f,g,o; zero initial
  * state; glass/modeling/recognition/recognizer_encoder.py:123-144).  The input projection
  * xg = x @ W_ih^T + b_ih + b_hh for both directions is computed beforehand with
- * glass_conv2d_nhwc: xg [R,T,2,4*Hd].  w_hh [2][4*Hd][Hd].  out [R,T,2*Hd] (fwd | bwd).  */
-int glass_bilstm_recurrence(const float* xg, const float* w_hh, float* out, int R, int T, int Hd, glass_stream_t stream);
+ * glass_conv2d_nhwc: xg [R,T,2,4*Hd] (direction-major, then gate-major i,f,g,o).
+ * w_hh_packed [2][Hd/4][4*Hd][4] (k-blocked, per direction).  out [R,T,2*Hd] (fwd | bwd).
+ * Requires Hd == 256.                                                                     */
+int glass_bilstm_recurrence(const float* xg, const float* w_hh_packed, float* out, int R, int T, int Hd,
+                            glass_stream_t stream);
 
 /* ------------------------------------------------------------------ attention decoder
  * Greedy additive-attention GRU decoder (AttentionRecognitionHead.sample,
  * glass/modeling/recognition/prediction_aster.py:63-99,247-266,291-302), all `max_len`
  * steps on device with no host sync; the reference's batch-global early break (rows of
  * steps after every RoI OF THE SAME IMAGE has emitted `eos` stay zero) is applied as a
- * mask using roi_image [R] (image id per RoI, non-decreasing).
- * x [R,T,D]; xproj [R,T,D] = xEmbed(x) precomputed with glass_conv2d_nhwc.
- * Weights: sW [D][D], sB [D], wW [D], wB [1], emb [C][D], w_ih [3D][2D], w_hh [3D][D],
- * b_ih [3D], b_hh [3D], fcW [C][D], fcB [C], temperature (host float).
- * out [R,max_len,C] softmax probabilities.                                               */
+ * mask using roi_image [R] (image id per RoI in [0,num_images), non-decreasing).
+ * x [R,T,D]; xproj [R,T,D] = xEmbed(x) precomputed with glass_conv2d_nhwc (it is
+ * step-invariant).  Weights (k-blocked packing above): sW [D/4][D][4], sB [D], wW [D],
+ * wB [1], emb [C][D] (row-major), w_ih [2D/4][3D][4] (input = [embedding | context]),
+ * w_hh [D/4][3D][4], b_ih [3D], b_hh [3D], fcW [D/4][C][4], fcB [C], temperature (host).
+ * out [R,max_len,C] softmax probabilities.  Requires D == 256, T <= 64, C <= 256.         */
 typedef struct glass_decoder_weights {
   const float *sW, *sB, *wW, *wB, *emb, *w_ih, *w_hh, *b_ih, *b_hh, *fcW, *fcB;
   float temperature;
 } glass_decoder_weights;
 int glass_attention_decode(const float* x, const float* xproj, const glass_decoder_weights* w, const int* roi_image, int R,
-                           int T, int D, int C, int max_len, int eos, float* out, glass_stream_t stream);
+                           int num_images, int T, int D, int C, int max_len, int eos, float* out, int* pred_scratch,
+                           glass_stream_t stream);
 
 #ifdef __cplusplus
 }
