@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py — GLASS inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (`GlassRCNN.inference`: preprocess -> ResNet-50+FPN ->
+rotated RPN -> box head -> rotated RoIAlign -> local extractor -> fusion attention -> recognizer)
+over one batch of 8 synthetic 1000x1000 images per GPU with 32 word RoIs per image
+(BASELINE.json configs[2] = the configuration the metric "images/sec/GPU end-to-end spotting,
+1000x1000, ~32 RoIs" is quoted on).  Inputs (float CHW images, injected word boxes) are resident
+in HBM before the timed region.  Because random-init weights do not yield ~32 sensible word
+detections, the RPN and box head run on their real 100 proposals and the recognition branch then
+runs on 32 injected boxes per image — no stage is skipped.
+With N > 1 every rank runs its own shard of images (weak scaling) and the per-image result records
+are exchanged by ONE RCCL all_gather per step, inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "glass-text-spotting_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BATCH = 8
+SIDE = 1000
+ROIS = 32
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--side", type=int, default=SIDE)
+    ap.add_argument("--rois", type=int, default=ROIS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-side", type=int, default=SIDE, help="image side of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+class ConvMeter:
+    """Wraps glass_conv2d_nhwc launches with HIP events on the launch stream (torch's current
+    stream = the stream every kernel of the path is enqueued on) and tallies algorithmic FLOPs."""
+
+    def __init__(self, K):
+        self.K = K
+        self.orig = K.conv2d_nhwc
+        self.events = []
+        self.flops = 0.0
+
+    def __enter__(self):
+        def wrapped(x, w, bias=None, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.orig(x, w, bias, **kw)
+            e1.record()
+            cout, kh, kw_, cin = w.shape
+            cin_real = 3 if cin == 4 else cin           # NHWC4-padded RGB inputs
+            self.flops += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin_real
+            self.events.append((e0, e1))
+            return y
+        self.K.conv2d_nhwc = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.K.conv2d_nhwc = self.orig
+
+    def total_ms(self):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.events)
+
+
+def cpu_baseline(cfg, sd, side, rois):
+    """Bounded CPU sample: the oracle (CPU restatement, kind='port') on ONE image of the workload."""
+    from glass_amd.utils.synth import make_boxes, make_image
+    from oracle import glass_cpu as O
+    n = torch.get_num_threads()
+    img = make_image(0, side, side).permute(2, 0, 1).float()
+    boxes = [make_boxes(0, rois, side, side)]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.glass_inference(sd, [img], cfg, injected_boxes=boxes)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": n, "kind": "port",
+            "sample": f"1 image {side}x{side}, {rois} injected RoIs, oracle/glass_cpu.py fp32 torch-CPU ({n} threads), "
+                      f"single cold run {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import glass_amd
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.distributed import all_gather_records, pack_results
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
+
+    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", f"cuda:{local_rank}"])
+    sd = make_state_dict(1234)
+    model = glass_amd.build_model(cfg)
+    model.load_state_dict(sd)
+
+    B = args.batch
+    gidx = [rank * B + i for i in range(B)]                      # global image indices of this rank's shard
+    images = [make_image(g, args.side, args.side).permute(2, 0, 1).float().contiguous().to(dev) for g in gidx]
+    boxes = [make_boxes(g, args.rois, args.side, args.side).to(dev) for g in gidx]
+    inputs = [{"image": im} for im in images]
+    max_det = cfg.TEST.DETECTIONS_PER_IMAGE
+    steps_txt = cfg.MODEL.ROI_RECOGNIZER_HEAD.MAX_WORD_LENGTH + 1
+
+    def step():
+        out = model.inference(inputs, override_boxes=boxes)
+        res = [o["instances"] for o in out]
+        rec = pack_results(res, max_det, steps_txt)
+        return all_gather_records(rec)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    line = None
+    if rank == 0:
+        # dominant kernel (conv_igemm_f32): one extra instrumented step, outside the timed region
+        with ConvMeter(K) as meter:
+            step()
+            conv_ms = meter.total_ms()
+            n_launch = len(meter.events)
+            conv_flops = meter.flops
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        line = {
+            "metric": "images/sec/GPU end-to-end spotting, 1000x1000, ~32 RoIs; 1/2/4/8 GPU scaling",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: backbone + RotatedROIAlign + recognition head, "
+                                   f"{args.rois} RoIs/img, bs={B}/GPU, {args.side}x{args.side} (padded to /32), fp32",
+                       "images_per_gpu_per_step": B, "rois_per_image": args.rois, "proposals_per_image": 100,
+                       "weights": "random-init (seed 1234), reference architecture",
+                       "parallelism": f"image-shard x{world}, 1 all_gather of result records/step"},
+            "images_per_sec_per_gpu": value / world,
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": n_launch, "algorithmic_gflop_per_launch": conv_flops / n_launch / 1e9,
+                         "avg_launch_ms": conv_ms / n_launch, "kernel_ms_per_step": conv_ms,
+                         "share_of_step": conv_ms / ms_per_step},
+            "whole_step_tflops": conv_flops / (ms_per_step * 1e-3) / 1e12,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_side, args.rois)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

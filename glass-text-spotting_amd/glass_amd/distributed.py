@@ -1,0 +1,97 @@
+"""Image sharding + result gather for multi-GPU inference (one process per GPU).
+
+The reference's only inference-time collective is `comm.gather(self._predictions, dst=0)` of pickled
+per-image results (reference glass/evaluation/text_evaluator.py:246-249).  Images are independent
+(SURVEY.md §8e), so ranks take disjoint image shards with no data-path collective; results are
+exchanged as ONE fixed-size record per image through a single `all_gather` (RCCL over xGMI on GPU,
+gloo in the CPU tests).  Record layout (float32, `MAX_DET` = TEST.DETECTIONS_PER_IMAGE slots):
+  [0]                       count
+  [1 : 1+5D]                boxes (cx,cy,w,h,angle)
+  [.. +D]                   scores
+  [.. +D]                   classes
+  [.. +2D]                  orientations (argmax, prob)
+  [.. +D*T]                 argmax character index per step      (reduced text payload)
+  [.. +D*T]                 its probability
+Full `[D,T,97]` probability tensors stay on the owning rank (1 MB/image; gather on request with
+`full_text_prob=True`).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .structures.core import Instances, RotatedBoxes
+
+
+def shard_indices(num_items: int, rank: int, world_size: int) -> List[int]:
+    """Contiguous block partition: item i -> rank floor(i * W / N); the union over ranks is
+    exactly range(num_items) with no overlap."""
+    lo = (num_items * rank) // world_size
+    hi = (num_items * (rank + 1)) // world_size
+    return list(range(lo, hi))
+
+
+def record_size(max_det: int, steps: int, classes: int = 0) -> int:
+    return 1 + max_det * (5 + 1 + 1 + 2 + 2 * steps + steps * classes)
+
+
+def pack_results(results: Sequence[Instances], max_det: int, steps: int, full_text_prob: bool = False,
+                 classes: int = 0) -> torch.Tensor:
+    """list[Instances] -> [n_images, record] float32 on the instances' device."""
+    dev = results[0].pred_boxes.tensor.device if len(results) else torch.device("cpu")
+    C = classes if full_text_prob else 0
+    rec = torch.zeros((len(results), record_size(max_det, steps, C)), dtype=torch.float32, device=dev)
+    D = max_det
+    for i, r in enumerate(results):
+        k = min(len(r), D)
+        rec[i, 0] = k
+        if k == 0:
+            continue
+        o = 1
+        rec[i, o:o + 5 * D].view(D, 5)[:k] = r.pred_boxes.tensor[:k]; o += 5 * D
+        rec[i, o:o + D][:k] = r.scores[:k]; o += D
+        rec[i, o:o + D][:k] = r.pred_classes[:k].float(); o += D
+        if r.has("orientations"):
+            rec[i, o:o + 2 * D].view(D, 2)[:k] = r.orientations[:k]
+        o += 2 * D
+        if r.has("pred_text_prob"):
+            p, idx = r.pred_text_prob[:k].max(dim=2)
+            rec[i, o:o + D * steps].view(D, steps)[:k] = idx.float()
+            rec[i, o + D * steps:o + 2 * D * steps].view(D, steps)[:k] = p
+            if C:
+                rec[i, o + 2 * D * steps:].view(D, steps, C)[:k] = r.pred_text_prob[:k]
+        o += 2 * D * steps
+    return rec
+
+
+def unpack_results(rec: torch.Tensor, image_sizes: Sequence[Tuple[int, int]], max_det: int, steps: int,
+                   classes: int = 0) -> List[Instances]:
+    out = []
+    D = max_det
+    for i, size in enumerate(image_sizes):
+        k = int(rec[i, 0].item())
+        o = 1
+        r = Instances(tuple(size))
+        r.pred_boxes = RotatedBoxes(rec[i, o:o + 5 * D].view(D, 5)[:k].clone()); o += 5 * D
+        r.scores = rec[i, o:o + D][:k].clone(); o += D
+        r.pred_classes = rec[i, o:o + D][:k].long(); o += D
+        r.orientations = rec[i, o:o + 2 * D].view(D, 2)[:k].clone(); o += 2 * D
+        r.pred_char_index = rec[i, o:o + D * steps].view(D, steps)[:k].long()
+        r.pred_char_prob = rec[i, o + D * steps:o + 2 * D * steps].view(D, steps)[:k].clone()
+        o += 2 * D * steps
+        if classes:
+            r.pred_text_prob = rec[i, o:].view(D, steps, classes)[:k].clone()
+        out.append(r)
+    return out
+
+
+def all_gather_records(local: torch.Tensor, group=None) -> torch.Tensor:
+    """[n_local, record] on every rank (same n_local) -> [world, n_local, record]; one collective."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local.unsqueeze(0)
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out
