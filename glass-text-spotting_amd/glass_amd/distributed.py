@@ -92,6 +92,6 @@ def all_gather_records(local: torch.Tensor, group=None) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local.unsqueeze(0)
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)      # rank-major concatenation
+    return out.view((world,) + tuple(local.shape))

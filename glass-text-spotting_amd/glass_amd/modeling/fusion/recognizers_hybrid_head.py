@@ -140,7 +140,8 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
                 r.pred_boxes = RotatedBoxes(b.to(device).float().contiguous())
                 r.scores = torch.ones((len(b),), dtype=torch.float32, device=device)
                 r.pred_classes = torch.zeros((len(b),), dtype=torch.int64, device=device)
-                r.orientations = torch.zeros((len(b), 2), dtype=torch.float32, device=device)
+                if self.box_predictor.orientation_on:
+                    r.orientations = torch.zeros((len(b), 2), dtype=torch.float32, device=device)
                 results.append(r)
         return self._recognize_into(img_nhwc4, feats, results)
 

@@ -27,7 +27,7 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
         super().__init__()
         self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
         assert self.num_classes == 1, "one foreground class ('word') is built (all reference configs)"
-        assert cfg.MODEL.ORIENTATION_ON, "orientation head expected ON (all reference configs)"
+        self.orientation_on = bool(cfg.MODEL.ORIENTATION_ON)     # off in glass_finetune_textocr.yaml
         self.class_names = [n.lower() for n in cfg.MODEL.ROI_HEADS.CLASS_NAMES]
         self.weights = tuple(float(v) for v in cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS)
         self.test_score_thresh = float(cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST)
@@ -36,7 +36,7 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
         self.w = {}
 
     def import_weights(self, sd, device, prefix: str) -> None:
-        names = ("cls_score", "bbox_pred", "orientation_pred")
+        names = ("cls_score", "bbox_pred") + (("orientation_pred",) if self.orientation_on else ())
         self.w = {"w": dev(torch.cat([sd[prefix + n + ".weight"] for n in names], 0), device),
                   "b": dev(torch.cat([sd[prefix + n + ".bias"] for n in names], 0), device)}
 
@@ -45,7 +45,8 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
         y = K.linear(x.contiguous(), self.w["w"], self.w["b"])
-        return y[:, 0:2].contiguous(), y[:, 2:7].contiguous(), y[:, 7:11].contiguous()
+        orient = y[:, 7:11].contiguous() if self.orientation_on else None
+        return y[:, 0:2].contiguous(), y[:, 2:7].contiguous(), orient
 
     def inference_batched(self, predictions, proposal_boxes: torch.Tensor, proposal_counts: torch.Tensor,
                           image_hw_dev: torch.Tensor):
@@ -53,11 +54,13 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
         Returns (boxes [N,K,5], scores [N,K], kept slot index [N,K], orientations [N*P,2], counts [N])."""
         scores, deltas, orient = predictions
         N, P, _ = proposal_boxes.shape
+        if orient is None:          # orientation head off: decode with dummy logits, field dropped later
+            orient = torch.zeros((scores.shape[0], 4), dtype=torch.float32, device=scores.device)
         boxes, fg, orient2 = K.box_decode(scores, deltas, orient, proposal_boxes.view(-1, 5), self.weights)
         ob, os_, oi, oc = K.rotated_nms_select(boxes.view(N, P, 5), fg.view(N, P), None, proposal_counts, image_hw_dev,
                                                self.test_score_thresh, self.test_nms_thresh,
                                                self.test_topk_per_image, K.NMS_CLIP)
-        return ob, os_, oi, orient2.view(N, P, 2), oc
+        return ob, os_, oi, (orient2.view(N, P, 2) if self.orientation_on else None), oc
 
     def inference(self, predictions, proposals: List[Instances]):
         """reference surface: list[Instances] with proposal_boxes -> (list[Instances], kept indices)."""
@@ -65,7 +68,8 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
         counts = [len(p) for p in proposals]
         N, P = len(proposals), max(counts + [1])
         pb = torch.zeros((N, P, 5), dtype=torch.float32, device=device)
-        sc = [torch.zeros((N * P, c), dtype=torch.float32, device=device) for c in (2, 5, 4)]
+        predictions = tuple(p for p in predictions if p is not None)
+        sc = [torch.zeros((N * P, p.shape[1]), dtype=torch.float32, device=device) for p in predictions]
         start = 0
         for n, p in enumerate(proposals):
             pb[n, : counts[n]] = p.proposal_boxes.tensor
@@ -74,7 +78,7 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
             start += counts[n]
         hw = torch.tensor([p.image_size for p in proposals], dtype=torch.int32, device=device)
         cnt = torch.tensor(counts, dtype=torch.int32, device=device)
-        ob, os_, oi, orient2, oc = self.inference_batched(tuple(sc), pb, cnt, hw)
+        ob, os_, oi, orient2, oc = self.inference_batched(tuple(sc) + ((None,) if len(sc) == 2 else ()), pb, cnt, hw)
         return self.to_instances(ob, os_, oi, orient2, oc, [p.image_size for p in proposals])
 
     @staticmethod
@@ -88,7 +92,8 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
             r.pred_boxes = RotatedBoxes(ob[n, :k])
             r.scores = os_[n, :k]
             r.pred_classes = torch.zeros((k,), dtype=torch.int64, device=ob.device)
-            r.orientations = orient2[n][idx]
+            if orient2 is not None:
+                r.orientations = orient2[n][idx]
             results.append(r)
             kept.append(idx)
         return results, kept

@@ -1,0 +1,19 @@
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace into the text table kept under profiles/.
+
+    python scripts/prof_summary.py gpurun_out/prof_r1/r1_results.db [steps] > profiles/r01_kernel_stats.txt
+"""
+import sqlite3
+import sys
+
+db = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+c = sqlite3.connect(db)
+rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                 "from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+print(f"# rocprofv3 --kernel-trace --stats summary of: python bench.py --steps 5 --warmup 2 --no-cpu-baseline")
+print(f"# source db: {db}; {steps} bench steps in the trace (warmup + timed + 1 metered)")
+print(f"# total kernel time {tot / 1e6:.2f} ms  ({tot / 1e6 / steps:.2f} ms per step)")
+print(f"{'Name':72s} {'Calls':>7s} {'TotalDurationNs':>16s} {'AverageNs':>12s} {'MinNs':>10s} {'MaxNs':>10s} {'Percentage':>10s}")
+for name, n, s, a, mn, mx in rows[:60]:
+    print(f"{name[:72]:72s} {n:7d} {s:16d} {a:12.1f} {mn:10d} {mx:10d} {100.0 * s / tot:10.2f}")
