@@ -41,15 +41,17 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p) {
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int A_LOADS = BM / 32;
   constexpr int B_LOADS = BN / 32;
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
-  float* As = smem;
-  float* Bs = smem + BM * LDS_LD;
+  // NSTAGE LDS stages: with 2, tile t is read by the MFMAs while tile t+1 is written (one barrier per
+  // k-tile); measured neutral vs 1 stage on MI355X (the 2 co-resident blocks already overlap), and one
+  // stage (36 KiB) keeps more blocks resident, which shortens the last partial wave of tiles.
+  constexpr int STAGE = (BM + BN) * LDS_LD;
+  __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
 
   // bijective XCD swizzle: XCD (bid % 8) owns a contiguous chunk of logical tile ids
   const int nblk = gridDim.x, bid = blockIdx.x;
@@ -120,7 +122,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p) {
       breg[i] = sel4(ok, v);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int stage) {
+    float* As = smem + stage * STAGE;
+    float* Bs = As + BM * LDS_LD;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i)
       *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + cc * 4]) = areg[i];
@@ -139,15 +143,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p) {
 
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
-  const float* a_frag = As + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
-  const float* b_frag = Bs + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
+  const float* a_frag0 = smem + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
+  const float* b_frag0 = smem + BM * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
 
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
   for (int kt = 0; kt < p.nk; ++kt) {
     const bool more = kt + 1 < p.nk;
     if (more) load_tile(kt + 1);
+    const int cur = NSTAGE == 2 ? (kt & 1) : 0;
+    const float* a_frag = a_frag0 + cur * STAGE;
+    const float* b_frag = b_frag0 + cur * STAGE;
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
       float4 af[TM], bf[TN];
@@ -168,10 +175,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p) {
         }
       }
     }
-    __syncthreads();
-    if (more) {
-      store_tile();
+    if (NSTAGE == 2) {
+      // stage (kt+1)&1 was last read in iteration kt-1, which every wave left through the barrier below
+      if (more) store_tile((kt + 1) & 1);
       __syncthreads();
+    } else {
+      __syncthreads();
+      if (more) {
+        store_tile(0);
+        __syncthreads();
+      }
     }
   }
 
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p) {
   }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW>
 static int launch_conv(ConvParams& p, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   p.tiles_m = cdiv(p.M, BM);
@@ -218,7 +231,7 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
     glass_set_error("glass_conv2d_nhwc: bad grid %ld", nblk);
     return GLASS_EINVAL;
   }
-  hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   GLASS_CHECK_LAUNCH("glass_conv2d_nhwc");
   return GLASS_OK;
 }
@@ -250,8 +263,8 @@ extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const
   p.Ktot = d->KH * d->KW * d->Cin;
   p.nk = cdiv(p.Ktot, BK);
   hipStream_t s = (hipStream_t)stream;
-  if (d->Cout <= 32) return launch_conv<4, 1, 2, 1>(p, s);   // 256 x 32
-  if (d->Cout <= 64) return launch_conv<4, 1, 2, 2>(p, s);   // 256 x 64
-  if (p.M <= 64) return launch_conv<1, 4, 2, 1>(p, s);       // 64 x 128 (few rows: linear layers)
-  return launch_conv<2, 2, 2, 2>(p, s);                      // 128 x 128
+  if (d->Cout <= 32) return launch_conv<4, 1, 1, 1, 1, 4>(p, s);   // 128 x 32
+  if (d->Cout <= 64) return launch_conv<2, 2, 2, 1, 1, 4>(p, s);   // 128 x 64
+  if (p.M <= 64) return launch_conv<1, 4, 2, 1, 1, 4>(p, s);       // 64 x 128 (few rows: linear layers)
+  return launch_conv<2, 2, 2, 2, 1, 3>(p, s);                      // 128 x 128, 3 blocks/CU
 }

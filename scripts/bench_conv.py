@@ -8,20 +8,25 @@ from glass_amd.ops import native as K
 dev = torch.device("cuda:0")
 LAYERS = [
     # name, N, H, W, Cin, Cout, k, stride, pad
-    ("stem7x7", 8, 1024, 1024, 4, 64, 7, 2, 3),
-    ("res2.conv2 3x3 64", 8, 256, 256, 64, 64, 3, 1, 1),
+    ("local l3 3x3 256 @16x33 R=256", 256, 16, 33, 256, 256, 3, 1, 1),
+    ("fpn_out2 3x3 256 @256", 8, 256, 256, 256, 256, 3, 1, 1),
+    ("rpn 3x3 256 @64", 8, 64, 64, 256, 256, 3, 1, 1),
     ("res2.conv3 1x1 64->256", 8, 256, 256, 64, 256, 1, 1, 0),
+    ("res3.conv3 1x1 128->512", 8, 128, 128, 128, 512, 1, 1, 0),
+    ("res4.conv3 1x1 256->1024", 8, 64, 64, 256, 1024, 1, 1, 0),
+    ("fpn_lat2 1x1 256->256 @256", 8, 256, 256, 256, 256, 1, 1, 0),
+    ("res2.conv2 3x3 64", 8, 256, 256, 64, 64, 3, 1, 1),
     ("res2.conv1 1x1 256->64", 8, 256, 256, 256, 64, 1, 1, 0),
     ("res3.conv2 3x3 128", 8, 128, 128, 128, 128, 3, 1, 1),
-    ("res4.conv2 3x3 256", 8, 64, 64, 256, 256, 3, 1, 1),
     ("res5.conv2 3x3 512", 8, 32, 32, 512, 512, 3, 1, 1),
-    ("res5.conv3 1x1 512->2048", 8, 32, 32, 512, 2048, 1, 1, 0),
-    ("fpn_out2 3x3 256 @256", 8, 256, 256, 256, 256, 3, 1, 1),
+    ("stem7x7", 8, 1024, 1024, 4, 64, 7, 2, 3),
+    ("local conv0_1 3x3 4->16 @128", 256, 128, 128, 4, 16, 3, 1, 1),
+    ("local conv0_2 3x3 16->32 @128", 256, 128, 128, 16, 32, 3, 1, 1),
     ("local l1 3x3 64 @64 R=256", 256, 64, 64, 64, 64, 3, 1, 1),
     ("local l2 3x3 128 @32 R=256", 256, 32, 32, 128, 128, 3, 1, 1),
-    ("local l3 3x3 256 @16x33 R=256", 256, 16, 33, 256, 256, 3, 1, 1),
     ("fusion out 3x3 512->256 R=256", 256, 8, 32, 512, 256, 3, 1, 1),
     ("fc1 800x12544->2048", 800, 1, 1, 12544, 2048, 1, 1, 0),
+    ("rpn p6 3x3 256 @16", 8, 16, 16, 256, 256, 3, 1, 1),
 ]
 for name, N, H, W, Cin, Cout, k, s, p in LAYERS:
     x = torch.randn((N, H, W, Cin), device=dev)
