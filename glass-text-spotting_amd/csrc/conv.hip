@@ -30,7 +30,7 @@ struct ConvParams {
   float* y;
   int N, H, W, Cin, Cout, KH, KW, sh, sw, ph, pw, Ho, Wo;
   int ldx, ldy, ycoff, ycs, relu, res_mode, ldr;
-  int M, Ktot, nk, tiles_m, tiles_n;
+  int M, Ktot, nk, tiles_m, tiles_n, vec_epi;
 };
 
 __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
@@ -188,8 +188,70 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     }
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
   const int HoWo2 = (p.Ho >> 1) * (p.Wo >> 1);
+  if (p.vec_epi) {
+    // Vector path (unit channel stride, 16-byte aligned rows): the accumulators are transposed through
+    // the (now idle) operand LDS so that every lane handles 4 consecutive channels of one pixel:
+    // 16-byte residual loads / output stores, 16 lanes covering 256 contiguous bytes of a row.
+    constexpr int CW = ((BM + BN) * LDS_LD >= BM * 68 && BN >= 64) ? 64 : 32;   // columns per staged chunk
+    constexpr int SLD = CW + 4;
+    constexpr int NCHUNK = BN / CW;
+    constexpr int VPR = CW / 4;                    // float4 per staged row
+    constexpr int ITERS = BM * VPR / 256;
+    float* stage = smem;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+      __syncthreads();                             // operand reads / previous chunk's read-back done
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col0 = (wn * TN + j) * 32;
+        if (col0 / CW == c) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+              stage[row * SLD + (col0 % CW) + (lane & 31)] = acc[i][j][e];
+            }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + 256 * it;
+        const int row = idx / VPR, c4 = idx - row * VPR;
+        const int m = m0 + row;
+        const int co = n0 + c * CW + c4 * 4;
+        if (m < p.M && co < p.Cout) {
+          float4 v = *reinterpret_cast<const float4*>(&stage[row * SLD + c4 * 4]);
+          if (p.bias != nullptr) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (p.res_mode != 0) {
+            long roff;
+            if (p.res_mode == 1) {
+              roff = (long)m * p.ldr + co;
+            } else {
+              const int n = m / HoWo;
+              const int rem = m - n * HoWo;
+              const int ho = rem / p.Wo;
+              const int wo = rem - ho * p.Wo;
+              roff = ((long)n * HoWo2 + (long)(ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * p.ldr + co;
+            }
+            const float4 r = *reinterpret_cast<const float4*>(p.res + roff);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          *reinterpret_cast<float4*>(p.y + (long)m * p.ldy + p.ycoff + co) = v;
+        }
+      }
+    }
+    return;
+  }
+  // Scalar path (channel-strided / unaligned outputs)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -262,6 +324,9 @@ extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const
   p.M = (int)M;
   p.Ktot = d->KH * d->KW * d->Cin;
   p.nk = cdiv(p.Ktot, BK);
+  p.vec_epi = (d->y_cstride == 1 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && d->Cout % 4 == 0 &&
+               ((uintptr_t)y & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
+               (d->res_mode == 0 || (d->ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0))) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (d->Cout <= 32) return launch_conv<4, 1, 1, 1, 1, 4>(p, s);   // 128 x 32
   if (d->Cout <= 64) return launch_conv<2, 2, 2, 1, 1, 4>(p, s);   // 128 x 64

@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ x
 #pragma unroll
       for (int r = 0; r < LSTM_RB; ++r)
         acc[g][r] = (r < nr) ? xg[(((long)(r0 + r) * T + t) * 2 + dir) * (4 * LSTM_HD) + g * LSTM_HD + u] : 0.f;
-#pragma unroll 4
     for (int k4 = 0; k4 < LSTM_HD / 4; ++k4) {
       float4 wv[4];
 #pragma unroll
@@ -249,7 +248,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
       float acc[DEC_RB];
 #pragma unroll
       for (int r = 0; r < DEC_RB; ++r) acc[r] = p.sB[u];
-#pragma unroll 8
       for (int k4 = 0; k4 < DEC_D / 4; ++k4) {
         const float4 wv = sW4[(long)k4 * DEC_D + u];
 #pragma unroll
@@ -293,7 +291,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
     for (int r = 0; r < DEC_RB; ++r) {
       float s = 0.f;
       if (r < nr)
-#pragma unroll 8
         for (int t = 0; t < T; ++t) s += energy[r][t] * p.x[((long)(r0 + r) * T + t) * DEC_D + u];
       inp[r][DEC_D + u] = s;
     }
@@ -305,7 +302,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
       for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int r = 0; r < DEC_RB; ++r) { gi[g][r] = p.b_ih[g * DEC_D + u]; gh[g][r] = p.b_hh[g * DEC_D + u]; }
-#pragma unroll 4
       for (int k4 = 0; k4 < 2 * DEC_D / 4; ++k4) {
         float4 wv[3];
 #pragma unroll
@@ -317,7 +313,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
           for (int g = 0; g < 3; ++g) gi[g][r] += wv[g].x * iv.x + wv[g].y * iv.y + wv[g].z * iv.z + wv[g].w * iv.w;
         }
       }
-#pragma unroll 4
       for (int k4 = 0; k4 < DEC_D / 4; ++k4) {
         float4 wv[3];
 #pragma unroll
@@ -344,7 +339,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
       float acc[DEC_RB];
 #pragma unroll
       for (int r = 0; r < DEC_RB; ++r) acc[r] = p.fcB[u];
-#pragma unroll 8
       for (int k4 = 0; k4 < DEC_D / 4; ++k4) {
         const float4 wv = fc4[(long)k4 * C + u];
 #pragma unroll
