@@ -171,6 +171,14 @@ def main():
             n_launch = len(meter.events)
             conv_flops = meter.flops
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant instantiation from the PMC passes kept under profiles/
+        # (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 x2 read correction applied)
+        traffic, mfma_util = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_summary.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                pj = json.load(f)
+            traffic, mfma_util = pj.get("hbm_bytes_per_launch_corrected"), pj.get("MfmaUtil_percent")
         line = {
             "metric": "images/sec/GPU end-to-end spotting, 1000x1000, ~32 RoIs; 1/2/4/8 GPU scaling",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,7 +192,9 @@ def main():
             "images_per_sec_per_gpu": value / world,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes/launch, PMC (profiles/r01_pmc_conv_summary.json), 128x128 instantiation",
+                         "mfma_util_percent_pmc": mfma_util,
                          "launches_per_step": n_launch, "algorithmic_gflop_per_launch": conv_flops / n_launch / 1e9,
                          "avg_launch_ms": conv_ms / n_launch, "kernel_ms_per_step": conv_ms,
                          "share_of_step": conv_ms / ms_per_step},
