@@ -68,13 +68,24 @@ class GlassRunner:
         return chw, scale_ratio
 
     def run_batch(self, images: Sequence[np.ndarray]) -> List[Instances]:
+        """Many images per step with per-image results identical to image-by-image calls.  detectron2
+        pads a batch to its largest image and the pad region is visible to the backbone/RPN, so images
+        are grouped by their own padded shape (multiple of 32) and each group is one model call."""
         inputs, ratios, shapes = [], [], []
         for im in images:
             t, r = self._image_to_tensor(im)
             inputs.append({"image": t, "height": t.shape[1], "width": t.shape[2]})
             ratios.append(r)
             shapes.append(im.shape[:2])
-        raw = self.model(inputs)
+        d = self.model.backbone.size_divisibility
+        groups = {}
+        for i, inp in enumerate(inputs):
+            key = ((inp["height"] + d - 1) // d * d, (inp["width"] + d - 1) // d * d)
+            groups.setdefault(key, []).append(i)
+        raw = [None] * len(inputs)
+        for idxs in groups.values():
+            for i, res in zip(idxs, self.model([inputs[i] for i in idxs])):
+                raw[i] = res
         out = []
         for res, r, (h, w) in zip(raw, ratios, shapes):
             preds = res["instances"]

@@ -126,12 +126,17 @@ class PostProcessorRotatedBoxes:
         return preds[preds.scores >= self.detect_threshold]
 
     def merge_intersecting_boxes(self, preds: Instances, ioa_threshold: float, pairs_height_ratio_thresh: float):
+        """Pair logic runs on host copies (<=100 boxes): the reference writes merged boxes back with
+        repeated indices (`tensor[pairs[:, 0]] = merged`, :175-176), whose result on the CPU path is
+        "last pair wins" — reproduced here with an explicit in-order loop so it is deterministic on any
+        device.  The IoA matrix and the 0.99 NMS run on the HIP kernels."""
         if len(preds) == 0:
             return preds
+        dev = preds.pred_boxes.tensor.device
         while True:
-            boxes = preds.pred_boxes.tensor
-            ioa = pairwise_ioa_rotated(boxes, boxes)
-            scores = preds.scores
+            boxes = preds.pred_boxes.tensor.detach().cpu().clone()
+            scores = preds.scores.detach().cpu()
+            ioa = pairwise_ioa_rotated(boxes.to(dev), boxes.to(dev)).cpu()
             pairs = torch.nonzero(ioa.fill_diagonal_(0).triu() >= self.minimal_ioa_thresh)
             if len(pairs) == 0:
                 break
@@ -147,10 +152,12 @@ class PostProcessorRotatedBoxes:
             if (~combined).all():
                 break
             vp = pairs[combined]
-            merged = self._merge_rotated_boxes(boxes[vp[:, 0]], boxes[vp[:, 1]], preds.scores[vp[:, 0]],
-                                               preds.scores[vp[:, 1]])
-            preds.pred_boxes.tensor[vp[:, 0]] = merged
-            preds.pred_boxes.tensor[vp[:, 1]] = merged.clone()
+            merged = self._merge_rotated_boxes(boxes[vp[:, 0]], boxes[vp[:, 1]], scores[vp[:, 0]], scores[vp[:, 1]])
+            for k in range(len(vp)):                       # tensor[vp[:, 0]] = merged   (last wins)
+                boxes[vp[k, 0]] = merged[k]
+            for k in range(len(vp)):                       # tensor[vp[:, 1]] = merged.clone()
+                boxes[vp[k, 1]] = merged[k]
+            preds.pred_boxes.tensor.copy_(boxes.to(dev))
             keep = nms_rotated(preds.pred_boxes.tensor, preds.scores, iou_threshold=0.99)
             preds = preds[keep]
         return preds

@@ -1,0 +1,96 @@
+"""GPU: the host tail (post-processing, runner) — product vs golden produced by the reference's own
+PostProcessorRotatedBoxes (oracle/make_golden.py --post), and GlassRunner vs the oracle pipeline."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(opts=()):
+    from glass_amd.config import get_glass_cfg
+    return get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), list(opts))
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C"])
+def test_rotated_box_postprocessor_matches_reference_golden(case, golden_dir):
+    from glass_amd.postprocess.post_processor_rotated_boxes import PostProcessorRotatedBoxes
+    from glass_amd.structures.core import Instances, RotatedBoxes
+    g = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    dev = torch.device("cuda:0")
+    inst = Instances((500, 500))
+    inst.pred_boxes = RotatedBoxes(torch.from_numpy(g[f"{case}_in_boxes"]).to(dev))
+    inst.scores = torch.from_numpy(g[f"{case}_in_scores"]).to(dev)
+    inst.pred_classes = torch.zeros(len(inst.scores), dtype=torch.int64, device=dev)
+    out = PostProcessorRotatedBoxes(_cfg())(inst)
+    assert len(out) == len(g[f"{case}_out_scores"])
+    np.testing.assert_allclose(out.scores.cpu().numpy(), g[f"{case}_out_scores"], atol=1e-6)
+    np.testing.assert_allclose(out.pred_boxes.tensor.cpu().numpy(), g[f"{case}_out_boxes"], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(out.pred_polygons.cpu().numpy(), g[f"{case}_out_polygons"], rtol=1e-4, atol=5e-3)
+
+
+def test_pairwise_ioa_and_nms_kernels_match_reference_golden(golden_dir):
+    from glass_amd.structures.boxes import nms_rotated, pairwise_ioa_rotated
+    from oracle import d2ops
+    g = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    b = torch.from_numpy(g["C_in_boxes"]).cuda()
+    ioa = pairwise_ioa_rotated(b, b).cpu().numpy()
+    np.testing.assert_allclose(ioa, g["C_ioa"], rtol=1e-4, atol=1e-5)
+    s = torch.from_numpy(g["C_in_scores"]).cuda()
+    for thr in (0.1, 0.3, 0.99):
+        assert nms_rotated(b, s, thr).cpu().tolist() == d2ops.nms_rotated(b.cpu(), s.cpu(), thr).tolist()
+    assert nms_rotated(b[:0], s[:0], 0.5).numel() == 0
+
+
+def test_runner_matches_oracle_and_batch_equals_single():
+    """GlassRunner (uint8 HWC in, resize policy, model, un-scale) vs the oracle pipeline; a batch gives the
+    same per-image results as image-by-image calls (reference semantics)."""
+    import torch.nn.functional as F
+    from glass_amd.inference.glass_runner import GlassRunner
+    from glass_amd.utils.synth import make_image, make_state_dict
+    from oracle import glass_cpu as O
+    # small sizes so the CPU oracle stays fast: min 160 / max 200 -> image 1 upscaled x1.6, image 2 shrunk
+    cfg = _cfg(["INPUT.MIN_SIZE_TEST", 160, "INPUT.MAX_SIZE_TEST", 200, "MODEL.DEVICE", "cuda:0"])
+    sd = make_state_dict(1234)
+    runner = GlassRunner(None, None, cfg=cfg, state_dict=sd, post_process=False)
+    # three images: two share a padded shape (one model call), the third is ragged (its own call)
+    imgs = [make_image(5, 100, 80).numpy(), make_image(6, 150, 250).numpy(), make_image(8, 98, 76).numpy()]
+    assert runner.get_inference_scale_ratio(imgs[0].shape) == 1.6 and runner.get_inference_scale_ratio(imgs[1].shape) == 0.8
+    single = [runner(im) for im in imgs]
+    batch = runner.run_batch(imgs)
+    for a, b in zip(single, batch):
+        assert len(a) == len(b)
+        np.testing.assert_allclose(a.pred_boxes.tensor.cpu().numpy(), b.pred_boxes.tensor.cpu().numpy(), atol=1e-4)
+        if len(a):
+            np.testing.assert_allclose(a.pred_text_prob.cpu().numpy(), b.pred_text_prob.cpu().numpy(), atol=1e-5)
+    for im, got in list(zip(imgs, single))[:2]:
+        r = runner.get_inference_scale_ratio(im.shape)
+        t = torch.from_numpy(im).permute(2, 0, 1).float()
+        nh, nw = int(np.round(r * im.shape[0])), int(np.round(r * im.shape[1]))
+        t = F.interpolate(t[None], size=(nh, nw), mode="bilinear", align_corners=False)[0]
+        ref = O.glass_inference(sd, [t], cfg)[0]
+        ref = O.meta_postprocess(ref, (nh, nw), (nh, nw), cfg.POST_PROCESSING.MIN_BOX_DIMENSION)
+        assert got.image_size == im.shape[:2]
+        assert len(got) == len(ref["scores"])
+        np.testing.assert_allclose(got.scores.cpu().numpy(), ref["scores"].numpy(), atol=1e-3)
+        ref_boxes = ref["pred_boxes"].clone()
+        ref_boxes[:, :4] /= r                       # isotropic un-scale (angle unchanged)
+        np.testing.assert_allclose(got.pred_boxes.tensor.cpu().numpy(), ref_boxes.numpy(), rtol=1e-4, atol=1e-2)
+
+
+def test_academic_postprocessor_runs_end_to_end():
+    """thresholds + merge + polygons + text-score filter on real model outputs; fields stay aligned"""
+    from glass_amd.inference.glass_runner import GlassRunner
+    from glass_amd.postprocess.post_processor_academic import get_instances_text
+    from glass_amd.utils.synth import make_image, make_state_dict
+    cfg = _cfg(["INPUT.MIN_SIZE_TEST", 128, "INPUT.MAX_SIZE_TEST", 256, "MODEL.DEVICE", "cuda:0",
+                "POST_PROCESSING.TEXT_THRESHOLD", 0.0])
+    runner = GlassRunner(None, None, cfg=cfg, state_dict=make_state_dict(1234), post_process=True)
+    out = runner(make_image(7, 128, 160).numpy())
+    n = len(out)
+    assert out.pred_polygons.shape == (n, 4, 2) and out.pred_text_prob.shape[0] == n
+    texts, scores, _ = get_instances_text(out.pred_text_prob, runner.text_encoder)
+    assert len(texts) == n and all(0.0 <= s <= 1.0 for s in scores)
