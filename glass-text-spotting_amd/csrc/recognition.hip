@@ -21,6 +21,50 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// acc[g][r] += sum_k W[g*gstride + u][k] * vec[r][k] for one output unit `u` per thread, weights in the
+// k-blocked layout (w4[k4 * rows_total + row] = 4 consecutive k of `row`).  L2 latency (~300 ns) is far
+// longer than one k-step of FMAs, so the weight stream runs PF k-steps ahead through a register ring
+// (statically indexed: fully unrolled), with the reload unconditional in the main loop and absent in
+// the tail (a predicated reload would make hipcc wait vmcnt(0) per element).
+template <int G, int RB, int PF>
+__device__ __forceinline__ void stream_matvec(const float4* __restrict__ w4, int rows_total, int gstride, int u, int K4,
+                                              const float* vec, int ldv, float (&acc)[G][RB]) {
+  float4 ring[PF][G];
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+#pragma unroll
+    for (int g = 0; g < G; ++g) ring[j][g] = w4[(long)j * rows_total + g * gstride + u];
+  int k0 = 0;
+#pragma unroll 1
+  for (; k0 + PF < K4; k0 += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      float4 wv[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        wv[g] = ring[j][g];
+        ring[j][g] = w4[(long)(k0 + PF + j) * rows_total + g * gstride + u];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const float4 hv = *reinterpret_cast<const float4*>(vec + r * ldv + (k0 + j) * 4);
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g][r] += wv[g].x * hv.x + wv[g].y * hv.y + wv[g].z * hv.z + wv[g].w * hv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const float4 hv = *reinterpret_cast<const float4*>(vec + r * ldv + (k0 + j) * 4);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        acc[g][r] += ring[j][g].x * hv.x + ring[j][g].y * hv.y + ring[j][g].z * hv.z + ring[j][g].w * hv.w;
+    }
+  }
+}
+
 // ================================================================== fusion attention
 // one workgroup (256 threads) per RoI; x slab [HW=256][C=512]
 constexpr int GC_C = 512, GC_HW = 256, GC_HEADS = 8, GC_P = 256;
@@ -172,18 +216,7 @@ __global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ x
 #pragma unroll
       for (int r = 0; r < LSTM_RB; ++r)
         acc[g][r] = (r < nr) ? xg[(((long)(r0 + r) * T + t) * 2 + dir) * (4 * LSTM_HD) + g * LSTM_HD + u] : 0.f;
-    for (int k4 = 0; k4 < LSTM_HD / 4; ++k4) {
-      float4 wv[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) wv[g] = w[(long)k4 * (4 * LSTM_HD) + g * LSTM_HD + u];
-#pragma unroll
-      for (int r = 0; r < LSTM_RB; ++r) {
-        const float4 hv = *reinterpret_cast<const float4*>(&h[r][k4 * 4]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc[g][r] += wv[g].x * hv.x + wv[g].y * hv.y + wv[g].z * hv.z + wv[g].w * hv.w;
-      }
-    }
+    stream_matvec<4, LSTM_RB, 4>(w, 4 * LSTM_HD, LSTM_HD, u, LSTM_HD / 4, &h[0][0], LSTM_HD, acc);
     __syncthreads();   // everyone has finished reading h of the previous step
 #pragma unroll
     for (int r = 0; r < LSTM_RB; ++r) {
@@ -245,19 +278,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
   for (int step = 0; step < p.max_len; ++step) {
     // ---- 1. sProj = sEmbed(h)
     {
-      float acc[DEC_RB];
+      float acc[1][DEC_RB];
 #pragma unroll
-      for (int r = 0; r < DEC_RB; ++r) acc[r] = p.sB[u];
-      for (int k4 = 0; k4 < DEC_D / 4; ++k4) {
-        const float4 wv = sW4[(long)k4 * DEC_D + u];
+      for (int r = 0; r < DEC_RB; ++r) acc[0][r] = p.sB[u];
+      stream_matvec<1, DEC_RB, 4>(sW4, DEC_D, 0, u, DEC_D / 4, &h[0][0], DEC_D, acc);
 #pragma unroll
-        for (int r = 0; r < DEC_RB; ++r) {
-          const float4 hv = *reinterpret_cast<const float4*>(&h[r][k4 * 4]);
-          acc[r] += wv.x * hv.x + wv.y * hv.y + wv.z * hv.z + wv.w * hv.w;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < DEC_RB; ++r) sproj[r][u] = acc[r];
+      for (int r = 0; r < DEC_RB; ++r) sproj[r][u] = acc[0][r];
     }
     __syncthreads();
     // ---- 2. energies e[r][t] = wEmbed(tanh(sProj + xProj[t])): wavefront per (r,t), lanes over D
@@ -302,28 +328,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
       for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int r = 0; r < DEC_RB; ++r) { gi[g][r] = p.b_ih[g * DEC_D + u]; gh[g][r] = p.b_hh[g * DEC_D + u]; }
-      for (int k4 = 0; k4 < 2 * DEC_D / 4; ++k4) {
-        float4 wv[3];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) wv[g] = wih4[(long)k4 * (3 * DEC_D) + g * DEC_D + u];
-#pragma unroll
-        for (int r = 0; r < DEC_RB; ++r) {
-          const float4 iv = *reinterpret_cast<const float4*>(&inp[r][k4 * 4]);
-#pragma unroll
-          for (int g = 0; g < 3; ++g) gi[g][r] += wv[g].x * iv.x + wv[g].y * iv.y + wv[g].z * iv.z + wv[g].w * iv.w;
-        }
-      }
-      for (int k4 = 0; k4 < DEC_D / 4; ++k4) {
-        float4 wv[3];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) wv[g] = whh4[(long)k4 * (3 * DEC_D) + g * DEC_D + u];
-#pragma unroll
-        for (int r = 0; r < DEC_RB; ++r) {
-          const float4 hv = *reinterpret_cast<const float4*>(&h[r][k4 * 4]);
-#pragma unroll
-          for (int g = 0; g < 3; ++g) gh[g][r] += wv[g].x * hv.x + wv[g].y * hv.y + wv[g].z * hv.z + wv[g].w * hv.w;
-        }
-      }
+      stream_matvec<3, DEC_RB, 4>(wih4, 3 * DEC_D, DEC_D, u, 2 * DEC_D / 4, &inp[0][0], 2 * DEC_D, gi);
+      stream_matvec<3, DEC_RB, 4>(whh4, 3 * DEC_D, DEC_D, u, DEC_D / 4, &h[0][0], DEC_D, gh);
       __syncthreads();   // all reads of the old state are done
 #pragma unroll
       for (int r = 0; r < DEC_RB; ++r) {
@@ -336,19 +342,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
     __syncthreads();
     // ---- 6. logits = fc(h) * temperature
     if (u < C) {
-      float acc[DEC_RB];
+      float acc[1][DEC_RB];
 #pragma unroll
-      for (int r = 0; r < DEC_RB; ++r) acc[r] = p.fcB[u];
-      for (int k4 = 0; k4 < DEC_D / 4; ++k4) {
-        const float4 wv = fc4[(long)k4 * C + u];
+      for (int r = 0; r < DEC_RB; ++r) acc[0][r] = p.fcB[u];
+      stream_matvec<1, DEC_RB, 4>(fc4, C, 0, u, DEC_D / 4, &h[0][0], DEC_D, acc);
 #pragma unroll
-        for (int r = 0; r < DEC_RB; ++r) {
-          const float4 hv = *reinterpret_cast<const float4*>(&h[r][k4 * 4]);
-          acc[r] += wv.x * hv.x + wv.y * hv.y + wv.z * hv.z + wv.w * hv.w;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < DEC_RB; ++r) logit[r][u] = acc[r] * p.temperature;
+      for (int r = 0; r < DEC_RB; ++r) logit[r][u] = acc[0][r] * p.temperature;
     }
     __syncthreads();
     // ---- 7. softmax over C classes + argmax (first maximum), one wavefront per RoI
