@@ -19,6 +19,7 @@
 // blockIdx -> tile map is XCD-aware: hardware places block b on XCD b%8 (each XCD has its
 // own 4 MiB L2), so each XCD gets a contiguous run of tiles whose neighbours share A rows.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -38,15 +39,16 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
+  constexpr int LDS_LD = BK + 4;
+  constexpr int KCH = BK / 4;            // 16-byte chunks per staged row
+  constexpr int RPP = 256 / KCH;         // rows staged per pass of the 256 threads
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
-  constexpr int A_LOADS = BM / 32;
-  constexpr int B_LOADS = BN / 32;
+  constexpr int A_LOADS = BM / RPP;
+  constexpr int B_LOADS = BN / RPP;
   // NSTAGE LDS stages: with 2, tile t is read by the MFMAs while tile t+1 is written (one barrier per
   // k-tile); measured neutral vs 1 stage on MI355X (the 2 co-resident blocks already overlap), and one
   // stage (36 KiB) keeps more blocks resident, which shortens the last partial wave of tiles.
@@ -63,15 +65,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int cc = tid & 7;    // 16-byte chunk column inside the k-tile
-  const int r0 = tid >> 3;   // first staged row of this thread (0..31)
+  const int cc = tid % KCH;  // 16-byte chunk column inside the k-tile
+  const int r0 = tid / KCH;  // first staged row of this thread
 
   long a_base[A_LOADS];
   int a_hi0[A_LOADS], a_wi0[A_LOADS];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
-    const int m = m0 + r0 + 32 * i;
+    const int m = m0 + r0 + RPP * i;
     if (m < p.M) {
       const int n = m / HoWo;
       const int rem = m - n * HoWo;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   bool b_ok[B_LOADS];
 #pragma unroll
   for (int i = 0; i < B_LOADS; ++i) {
-    const int co = n0 + r0 + 32 * i;
+    const int co = n0 + r0 + RPP * i;
     b_ok[i] = co < p.Cout;
     b_off[i] = (long)(b_ok[i] ? co : 0) * p.Ktot + cc * 4;
   }
@@ -127,10 +129,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     float* Bs = As + BM * LDS_LD;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i)
-      *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * LDS_LD + cc * 4]) = areg[i];
+      *reinterpret_cast<float4*>(&As[(r0 + RPP * i) * LDS_LD + cc * 4]) = areg[i];
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
-      *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * LDS_LD + cc * 4]) = breg[i];
+      *reinterpret_cast<float4*>(&Bs[(r0 + RPP * i) * LDS_LD + cc * 4]) = breg[i];
   };
 
   f32x16 acc[TM][TN];
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK>
 static int launch_conv(ConvParams& p, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   p.tiles_m = cdiv(p.M, BM);
@@ -293,7 +295,8 @@ static int launch_conv(ConvParams& p, hipStream_t stream) {
     glass_set_error("glass_conv2d_nhwc: bad grid %ld", nblk);
     return GLASS_EINVAL;
   }
-  hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  p.nk = cdiv(p.Ktot, BK);
+  hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   GLASS_CHECK_LAUNCH("glass_conv2d_nhwc");
   return GLASS_OK;
 }
@@ -323,13 +326,16 @@ extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const
   GLASS_CHECK_ARG(M < 0x7fffffffL, "glass_conv2d_nhwc: too many output pixels");
   p.M = (int)M;
   p.Ktot = d->KH * d->KW * d->Cin;
-  p.nk = cdiv(p.Ktot, BK);
   p.vec_epi = (d->y_cstride == 1 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && d->Cout % 4 == 0 &&
                ((uintptr_t)y & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
                (d->res_mode == 0 || (d->ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0))) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (d->Cout <= 32) return launch_conv<4, 1, 1, 1, 1, 4>(p, s);   // 128 x 32
-  if (d->Cout <= 64) return launch_conv<2, 2, 2, 1, 1, 4>(p, s);   // 128 x 64
-  if (p.M <= 64) return launch_conv<1, 4, 2, 1, 1, 4>(p, s);       // 64 x 128 (few rows: linear layers)
-  return launch_conv<2, 2, 2, 2, 1, 3>(p, s);                      // 128 x 128, 3 blocks/CU
+  if (d->Cout <= 32) return launch_conv<4, 1, 1, 1, 1, 4, 32>(p, s);   // 128 x 32
+  if (d->Cout <= 64) return launch_conv<2, 2, 2, 1, 1, 4, 32>(p, s);   // 128 x 64
+  // few 128x128 tiles (deep small maps, linear layers on <=800 rows): halve the tile height so the
+  // grid covers the 256 CUs at least ~2x
+  const long tiles128 = (long)cdiv(p.M, 128) * cdiv(d->Cout, 128);
+  if (p.M <= 64 || tiles128 < 640) return launch_conv<1, 4, 2, 1, 1, 4, 32>(p, s);   // 64 x 128
+  return launch_conv<2, 2, 2, 2, 1, 3, 32>(p, s);                      // 128 x 128, 3 blocks/CU
+  // (measured on MI355X: BK=64 with 2 blocks/CU and a 2-stage LDS pipeline are both within 2% of this)
 }
