@@ -108,13 +108,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("GLASS_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only to
+    dev_index = local_rank % ndev                                 # exercise the N>1 plumbing on a 1-GPU box
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import glass_amd
     from glass_amd.config import get_glass_cfg
@@ -122,7 +128,7 @@ def main():
     from glass_amd.ops import native as K
     from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
 
-    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", f"cuda:{local_rank}"])
+    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", f"cuda:{dev_index}"])
     sd = make_state_dict(1234)
     model = glass_amd.build_model(cfg)
     model.load_state_dict(sd)
@@ -139,6 +145,8 @@ def main():
         out = model.inference(inputs, override_boxes=boxes)
         res = [o["instances"] for o in out]
         rec = pack_results(res, max_det, steps_txt)
+        if dist is not None and backend != "nccl":
+            return all_gather_records(rec.cpu())
         return all_gather_records(rec)
 
     def barrier():
@@ -156,7 +164,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
