@@ -141,10 +141,13 @@ def main():
     max_det = cfg.TEST.DETECTIONS_PER_IMAGE
     steps_txt = cfg.MODEL.ROI_RECOGNIZER_HEAD.MAX_WORD_LENGTH + 1
 
-    def step():
+    def local_step():
         out = model.inference(inputs, override_boxes=boxes)
         res = [o["instances"] for o in out]
-        rec = pack_results(res, max_det, steps_txt)
+        return pack_results(res, max_det, steps_txt)
+
+    def step():
+        rec = local_step()
         if dist is not None and backend != "nccl":
             return all_gather_records(rec.cpu())
         return all_gather_records(rec)
@@ -173,8 +176,9 @@ def main():
     line = None
     if rank == 0:
         # dominant kernel (conv_igemm_f32): one extra instrumented step, outside the timed region
+        # (rank-local: must not enter a collective the other ranks are not in)
         with ConvMeter(K) as meter:
-            step()
+            local_step()
             conv_ms = meter.total_ms()
             n_launch = len(meter.events)
             conv_flops = meter.flops
