@@ -5,171 +5,7 @@
 // candidates per NMS chunk (one wavefront-width bitmask row per candidate).
 #include "common.h"
 
-typedef unsigned long long u64;
-typedef unsigned int u32;
-
-// ------------------------------------------------------------------ helpers
-__device__ __forceinline__ u32 float_key(float f) {
-  // order-preserving map float -> uint (larger float => larger key); -0 < +0 is harmless here
-  u32 u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_float(u32 k) {
-  u32 u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-  return __uint_as_float(u);
-}
-
-// descending bitonic sort of `npad` (power of two) u64 in LDS by all threads of the block
-__device__ void bitonic_sort_desc(u64* a, int npad) {
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npad; i += blockDim.x) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const u64 x = a[i], y = a[ixj];
-          const bool desc = (i & k) == 0;
-          if (desc ? (x < y) : (x > y)) { a[i] = y; a[ixj] = x; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// ------------------------------------------------------------------ RPN: top-k + decode
-constexpr int TOPK_MAX = 2048;
-constexpr float SCALE_CLAMP = 4.135166556742356f;  // log(1000/16)
-
-struct RpnParams {
-  const float* logits; const float* deltas; const float* cell;
-  int ldl, ldd, N, H, W, A, stride;
-  float anchor_offset, wx, wy, ww, wh, wa;
-  int topk, level_id, slot_off, slots;
-  float* out_boxes; float* out_scores; int* out_level;
-};
-
-__device__ __forceinline__ float floor_mod(float a, float b) {  // torch.remainder semantics
-  float m = fmodf(a, b);
-  if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
-  return m;
-}
-
-__global__ __launch_bounds__(1024) void rpn_topk_decode_kernel(RpnParams p) {
-  __shared__ u32 hist[256];
-  __shared__ u64 sel[TOPK_MAX];
-  __shared__ u64 s_prefix;
-  __shared__ int s_krem, s_done, s_cnt;
-  const int n = blockIdx.x;
-  const int total = p.H * p.W * p.A;
-  const int k = p.topk < total ? p.topk : total;
-  const float* lg = p.logits + (long)n * p.H * p.W * p.ldl;
-  const bool dense = (p.ldl == p.A);   // logits contiguous -> flat index == memory index
-
-  auto composite = [&](int i) -> u64 {
-    const float v = dense ? lg[i] : lg[(long)(i / p.A) * p.ldl + (i % p.A)];
-    // NaN sorts as the largest value in torch.sort(descending) -> give it the top key
-    const u32 key = (v != v) ? 0xffffffffu : float_key(v);
-    return ((u64)key << 32) | (u64)(0xffffffffu - (u32)i);   // ties: lower index first
-  };
-
-  // MSD radix select on the 64-bit composite (8 bits / pass); all composites are distinct,
-  // so the k-th largest is unique.  Stops early once a whole bucket is taken.
-  if (threadIdx.x == 0) { s_prefix = 0; s_krem = k; s_done = 0; }
-  __syncthreads();
-  u64 thr = 0;   // select all composites >= thr
-  for (int pass = 0; pass < 8; ++pass) {
-    const int shift = 56 - 8 * pass;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    const u64 prefix = s_prefix;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      const u64 c = composite(i);
-      if (pass == 0 || (c >> (shift + 8)) == prefix) atomicAdd(&hist[(u32)(c >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int krem = s_krem, b = 255;
-      u32 cum = 0;
-      for (; b >= 0; --b) {
-        if (cum + hist[b] >= (u32)krem) break;
-        cum += hist[b];
-      }
-      // bucket b holds the k-th element; `cum` elements are in strictly higher buckets
-      s_prefix = (prefix << 8) | (u64)b;
-      s_krem = krem - (int)cum;
-      if (hist[b] == (u32)(krem - (int)cum)) s_done = 1;   // take the whole bucket
-    }
-    __syncthreads();
-    thr = s_prefix << shift;
-    if (s_done || pass == 7) break;
-  }
-  // compaction (unordered) + sort
-  if (threadIdx.x == 0) s_cnt = 0;
-  __syncthreads();
-  int npad = 1;
-  while (npad < k) npad <<= 1;
-  for (int i = threadIdx.x; i < npad; i += blockDim.x) sel[i] = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const u64 c = composite(i);
-    if (c >= thr) {
-      const int slot = atomicAdd(&s_cnt, 1);
-      if (slot < TOPK_MAX) sel[slot] = c;
-    }
-  }
-  __syncthreads();
-  bitonic_sort_desc(sel, npad);
-  // decode the selected anchors
-  for (int j = threadIdx.x; j < k; j += blockDim.x) {
-    const u64 c = sel[j];
-    const int i = (int)(0xffffffffu - (u32)(c & 0xffffffffu));
-    const int a = i % p.A;
-    const int cellidx = i / p.A;
-    const int w = cellidx % p.W, h = cellidx / p.W;
-    const float score = dense ? lg[i] : lg[(long)cellidx * p.ldl + a];
-    const float* d = p.deltas + ((long)n * p.H * p.W + cellidx) * p.ldd + a * 5;
-    const float acx = (float)w * (float)p.stride + p.anchor_offset * (float)p.stride;
-    const float acy = (float)h * (float)p.stride + p.anchor_offset * (float)p.stride;
-    const float aw = p.cell[a * 5 + 2], ah = p.cell[a * 5 + 3], aa = p.cell[a * 5 + 4];
-    const float dx = d[0] / p.wx, dy = d[1] / p.wy;
-    float dw = d[2] / p.ww, dh = d[3] / p.wh;
-    const float da = d[4] / p.wa;
-    dw = fminf(dw, SCALE_CLAMP);
-    dh = fminf(dh, SCALE_CLAMP);
-    float* ob = p.out_boxes + ((long)n * p.slots + p.slot_off + j) * 5;
-    ob[0] = dx * aw + acx;
-    ob[1] = dy * ah + acy;
-    ob[2] = expf(dw) * aw;
-    ob[3] = expf(dh) * ah;
-    const float pa = da * 180.0f / 3.14159265358979323846f + aa;
-    ob[4] = floor_mod(pa + 180.0f, 360.0f) - 180.0f;
-    p.out_scores[(long)n * p.slots + p.slot_off + j] = score;
-    p.out_level[(long)n * p.slots + p.slot_off + j] = p.level_id;
-  }
-}
-
-extern "C" int glass_rpn_level_topk_decode(const float* logits, int ldl, const float* deltas, int ldd, int N, int H, int W,
-                                           int A, int stride, float anchor_offset, const float* cell_anchors_dev,
-                                           const float* weights5_host, int topk, int level_id, int slot_off,
-                                           int slots_per_image, float* out_boxes, float* out_scores, int* out_level,
-                                           glass_stream_t stream) {
-  GLASS_CHECK_ARG(logits && deltas && cell_anchors_dev && weights5_host && out_boxes && out_scores && out_level,
-                  "glass_rpn_level_topk_decode: null pointer");
-  GLASS_CHECK_ARG(topk > 0 && topk <= TOPK_MAX, "glass_rpn_level_topk_decode: topk=%d (max %d)", topk, TOPK_MAX);
-  GLASS_CHECK_ARG(H > 0 && W > 0 && A > 0 && ldl >= A && ldd >= 5 * A, "glass_rpn_level_topk_decode: bad dims");
-  const int k = topk < H * W * A ? topk : H * W * A;
-  GLASS_CHECK_ARG(slot_off >= 0 && slot_off + k <= slots_per_image, "glass_rpn_level_topk_decode: slots overflow");
-  if (N == 0) return GLASS_OK;
-  RpnParams p;
-  p.logits = logits; p.deltas = deltas; p.cell = cell_anchors_dev; p.ldl = ldl; p.ldd = ldd; p.N = N; p.H = H; p.W = W;
-  p.A = A; p.stride = stride; p.anchor_offset = anchor_offset;
-  p.wx = weights5_host[0]; p.wy = weights5_host[1]; p.ww = weights5_host[2]; p.wh = weights5_host[3]; p.wa = weights5_host[4];
-  p.topk = topk; p.level_id = level_id; p.slot_off = slot_off; p.slots = slots_per_image;
-  p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_level = out_level;
-  hipLaunchKernelGGL(rpn_topk_decode_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, p);
-  GLASS_CHECK_LAUNCH("glass_rpn_level_topk_decode");
-  return GLASS_OK;
-}
+#include "proposal_common.h"
 
 // ------------------------------------------------------------------ rotated IoU (d2 box_iou_rotated_utils.h)
 struct Pt { float x, y; };

@@ -85,14 +85,18 @@ class RotatedRPN(InferenceModule):
         cand_scores = torch.empty((N, S), dtype=torch.float32, device=device)
         cand_level = torch.empty((N, S), dtype=torch.int32, device=device)
         off = 0
+        levels, keep_alive = [], []
         for lvl, f in enumerate(feats_nhwc):
             t = K.conv2d_nhwc(f, *self.w["conv"], padding=1, relu=1)
             head = K.conv2d_nhwc(t, *self.w["heads"])            # [N,H,W,6A]: logits | deltas
+            keep_alive.append(head)
             ld = head.shape[-1]
-            K.rpn_level_topk_decode(head, ld, head.view(-1)[A:], ld, N, f.shape[1], f.shape[2], A, 2 ** (lvl + 2),
-                                    self.anchor_offset, self.cell_anchors[lvl], self.weights, self.pre_nms_topk, lvl, off,
-                                    cand_boxes, cand_scores, cand_level)
+            levels.append({"logits": head, "deltas": head.view(-1)[A:], "ldl": ld, "ldd": ld, "H": f.shape[1],
+                           "W": f.shape[2], "stride": 2 ** (lvl + 2), "cell_anchors": self.cell_anchors[lvl],
+                           "topk": self.pre_nms_topk, "slot_off": off})
             off += ks[lvl]
+        # one chip-wide radix select over all levels and images (6 launches per step)
+        K.rpn_topk_decode(levels, N, A, self.anchor_offset, self.weights, cand_boxes, cand_scores, cand_level)
         boxes, scores, _, counts = K.rotated_nms_select(
             cand_boxes, cand_scores, cand_level, None, image_hw_dev, float("-inf"), self.nms_thresh, self.post_nms_topk,
             K.NMS_CLIP | K.NMS_DROP_EMPTY)

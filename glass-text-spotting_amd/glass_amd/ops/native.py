@@ -171,18 +171,29 @@ def _i32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
-def rpn_level_topk_decode(logits: torch.Tensor, ldl: int, deltas: torch.Tensor, ldd: int, N: int, H: int, W: int, A: int,
-                          stride: int, anchor_offset: float, cell_anchors: torch.Tensor, weights: Sequence[float], topk: int,
-                          level_id: int, slot_off: int, out_boxes: torch.Tensor, out_scores: torch.Tensor,
-                          out_level: torch.Tensor) -> None:
-    """`logits`/`deltas` may be channel slices of one head tensor (pass the sliced view's
-    data pointer through `.data_ptr()` of a narrow()ed tensor; ld* is the pixel stride)."""
+class RpnLevel(ctypes.Structure):
+    _fields_ = [("logits", c_void_p), ("deltas", c_void_p), ("cell_anchors", c_void_p)] + \
+               [(n, c_int) for n in ("ldl", "ldd", "H", "W", "stride", "topk", "slot_off")]
+
+
+def rpn_topk_decode(levels: Sequence[dict], N: int, A: int, anchor_offset: float, weights: Sequence[float],
+                    out_boxes: torch.Tensor, out_scores: torch.Tensor, out_level: torch.Tensor) -> None:
+    """levels: dicts with logits/deltas (device tensors whose data_ptr is the first element; may be channel
+    slices of one head tensor), ldl/ldd (pixel strides), H, W, stride, cell_anchors, topk, slot_off."""
+    L = len(levels)
+    arr = (RpnLevel * L)()
+    for i, lv in enumerate(levels):
+        arr[i].logits, arr[i].deltas = _dev(lv["logits"]), _dev(lv["deltas"])
+        arr[i].cell_anchors = _dev(lv["cell_anchors"])
+        for k in ("ldl", "ldd", "H", "W", "stride", "topk", "slot_off"):
+            setattr(arr[i], k, int(lv[k]))
+    nbytes = int(lib().glass_rpn_workspace_bytes(N, L))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=out_boxes.device)
     w = (c_float * 5)(*[float(v) for v in weights])
-    S = out_boxes.shape[1]
-    check(lib().glass_rpn_level_topk_decode(
-        c_void_p(_dev(logits)), int(ldl), c_void_p(_dev(deltas)), int(ldd), N, H, W, A, int(stride), c_float(anchor_offset),
-        c_void_p(_dev(cell_anchors)), w, int(topk), int(level_id), int(slot_off), int(S), c_void_p(_dev(out_boxes)),
-        c_void_p(_dev(out_scores)), c_void_p(_dev(out_level)), c_void_p(stream_handle())), "glass_rpn_level_topk_decode")
+    check(lib().glass_rpn_topk_decode(arr, L, N, A, c_float(anchor_offset), w, int(out_boxes.shape[1]),
+                                      c_void_p(_dev(out_boxes)), c_void_p(_dev(out_scores)), c_void_p(_dev(out_level)),
+                                      c_void_p(_dev(ws)), ctypes.c_int64(nbytes), c_void_p(stream_handle())),
+          "glass_rpn_topk_decode")
 
 
 NMS_CLIP, NMS_DROP_EMPTY = 1, 2

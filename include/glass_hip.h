@@ -100,17 +100,25 @@ int glass_roi_align_rotated(const glass_roialign_desc* d, const float* boxes, co
                             glass_stream_t stream);
 
 /* ------------------------------------------------------------------ rotated-box proposals
- * RRPN proposal selection for ONE pyramid level of a batch (d2 RRPN.predict_proposals +
- * find_top_rrpn_proposals, reached from glass/modeling/meta_arch/glass_rcnn.py:87):
- * per image, the `topk` highest objectness logits (descending, ties by lower index) are
- * selected, their anchors generated analytically, deltas applied
- * (Box2BoxTransformRotated), and written to out_boxes[n][slot_off + i] / out_scores /
- * out_level.  logits: [N,H,W,A] (pixel stride ldl), deltas: [N,H,W,A*5] (pixel stride ldd).
- * cell_anchors_dev: [A,5] on device ((.,.,w,h,angle) per anchor).  topk <= 2048.                 */
-int glass_rpn_level_topk_decode(const float* logits, int ldl, const float* deltas, int ldd, int N, int H, int W, int A,
-                                int stride, float anchor_offset, const float* cell_anchors_dev, const float* weights5_host,
-                                int topk, int level_id, int slot_off, int slots_per_image, float* out_boxes,
-                                float* out_scores, int* out_level, glass_stream_t stream);
+ * RRPN proposal selection for a whole batch and all pyramid levels (d2 RRPN.predict_proposals +
+ * find_top_rrpn_proposals, reached from glass/modeling/meta_arch/glass_rcnn.py:87): per image and
+ * level, the `topk` highest objectness logits in descending order (ties -> lower flat index
+ * (h,w,a), i.e. a stable descending sort) are selected, their anchors generated analytically,
+ * deltas applied (Box2BoxTransformRotated with `weights5_host`), and written to
+ * out_boxes[n][slot_off + i] / out_scores / out_level (= level index).
+ * logits: [N,H,W,A] with pixel stride ldl; deltas: [N,H,W,A*5] with pixel stride ldd (both may be
+ * channel slices of one head tensor); cell_anchors: [A,5] on device ((.,.,w,h,angle) per anchor).
+ * topk <= 2048, num_levels <= 8.  `workspace` is device scratch of >= glass_rpn_workspace_bytes().  */
+typedef struct glass_rpn_level {
+  const float* logits;
+  const float* deltas;
+  const float* cell_anchors;
+  int ldl, ldd, H, W, stride, topk, slot_off;
+} glass_rpn_level;
+int64_t glass_rpn_workspace_bytes(int N, int num_levels);
+int glass_rpn_topk_decode(const glass_rpn_level* levels, int num_levels, int N, int A, float anchor_offset,
+                          const float* weights5_host, int slots_per_image, float* out_boxes, float* out_scores,
+                          int* out_level, void* workspace, int64_t workspace_bytes, glass_stream_t stream);
 
 /* Per image: drop non-finite rows, drop rows with score <= score_thresh, clip (|angle| <= 1
  * deg only; flag GLASS_NMS_CLIP), drop empty boxes (flag GLASS_NMS_DROP_EMPTY), sort by

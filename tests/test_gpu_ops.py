@@ -141,3 +141,45 @@ def test_preprocess_and_resize():
     exp = torch.zeros(64, 64, 4)
     exp[:37, :53, :3] = (img.float() - torch.tensor(mean))
     assert torch.equal(b[1], exp) and (b[0] == 7).all()
+
+
+@pytest.mark.parametrize("mode", ["random", "ties", "constant", "small"])
+def test_rpn_topk_decode_matches_stable_sort(mode):
+    """chip-wide radix select vs torch's stable descending sort + the oracle's anchor/delta decode; covers
+    heavy ties (order = lower flat index first), the exact fallback (constant map) and k > H*W*A."""
+    from glass_amd.ops import native as K
+    from oracle import d2ops
+    dev = _dev()
+    N, A, topk = 2, 12, 1000
+    shapes = [(40, 52), (20, 26), (10, 13)] if mode != "small" else [(8, 9), (4, 5)]
+    g = torch.Generator().manual_seed(3)
+    heads, levels, refs = [], [], []
+    off = 0
+    cells = [d2ops.rotated_cell_anchors(16 << i, (0.2, 0.5, 1.0), (-90, -45, 0, 45)) for i in range(len(shapes))]
+    weights = (1.0, 1.0, 1.0, 1.0, 2.0)
+    for i, (H, W) in enumerate(shapes):
+        head = torch.randn((N, H, W, 6 * A), generator=g)
+        if mode == "ties":
+            head[..., :A] = torch.round(head[..., :A] * 2) / 2
+        elif mode == "constant":
+            head[..., :A] = 0.25
+        heads.append(head.to(dev).contiguous())
+        k = min(topk, H * W * A)
+        lg = head[..., :A].reshape(N, -1)
+        dl = head[..., A:].reshape(N, -1, 5)
+        anchors = d2ops.rotated_grid_anchors(H, W, 4 << i, cells[i])
+        srt, idx = lg.sort(dim=1, descending=True, stable=True)
+        boxes = torch.stack([d2ops.apply_deltas_rotated(dl[n][idx[n, :k]], anchors[idx[n, :k]], weights) for n in range(N)])
+        refs.append((srt[:, :k], boxes, off, k))
+        levels.append({"logits": heads[-1], "deltas": heads[-1].view(-1)[A:], "ldl": 6 * A, "ldd": 6 * A, "H": H, "W": W,
+                       "stride": 4 << i, "cell_anchors": cells[i].to(dev), "topk": topk, "slot_off": off})
+        off += k
+    ob = torch.zeros((N, off, 5), device=dev)
+    os_ = torch.zeros((N, off), device=dev)
+    ol = torch.full((N, off), -1, dtype=torch.int32, device=dev)
+    K.rpn_topk_decode(levels, N, A, 0.0, weights, ob, os_, ol)
+    torch.cuda.synchronize()
+    for i, (srt, boxes, o, k) in enumerate(refs):
+        assert torch.equal(os_[:, o:o + k].cpu(), srt), f"level {i}: selected logits / order differ"
+        np.testing.assert_allclose(ob[:, o:o + k].cpu().numpy(), boxes.numpy(), rtol=1e-5, atol=1e-4)
+        assert (ol[:, o:o + k] == i).all()
