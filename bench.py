@@ -124,7 +124,7 @@ def main():
 
     import glass_amd
     from glass_amd.config import get_glass_cfg
-    from glass_amd.distributed import all_gather_records, pack_results
+    from glass_amd.distributed import all_gather_records, pack_padded
     from glass_amd.ops import native as K
     from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
 
@@ -142,9 +142,8 @@ def main():
     steps_txt = cfg.MODEL.ROI_RECOGNIZER_HEAD.MAX_WORD_LENGTH + 1
 
     def local_step():
-        out = model.inference(inputs, override_boxes=boxes)
-        res = [o["instances"] for o in out]
-        return pack_results(res, max_det, steps_txt)
+        model.inference(inputs, override_boxes=boxes)            # list[{"instances": Instances}] (views) ...
+        return pack_padded(model.last_batch, max_det, steps_txt)  # ... + the padded batch for the gather
 
     def step():
         rec = local_step()

@@ -1,0 +1,122 @@
+// Batched tail of the meta-architecture: GlassRCNN._postprocess for every image of the step in ONE
+// launch (small-box filter -> RotatedBoxes.scale -> clip -> drop empty), with ordered compaction of
+// all per-detection fields (boxes, scores, orientations, the [T,C] text-probability rows), so the host
+// only reads N counts and slices views — instead of ~60 tiny elementwise launches per image.
+// HBM-bound copy work: the text rows (T*C floats each) are moved with float4-free scalar coalesced
+// loops (C = 97 is odd), one workgroup per image.
+#include "common.h"
+
+struct DetParams {
+  const float* boxes; const float* scores; const float* orient; const float* text;
+  const int* counts; const int* roi_start; const float* scale_xy; const int* out_hw;
+  int N, K, TC;
+  float min_box_dim;
+  int do_filter_small;
+  float* out_boxes; float* out_scores; float* out_orient; float* out_text; int* out_count;
+};
+
+__device__ __forceinline__ float floor_mod_f(float a, float b) {
+  float m = fmodf(a, b);
+  if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
+  return m;
+}
+
+__global__ __launch_bounds__(256) void detections_finalize_kernel(DetParams p) {
+  __shared__ int keep_src[1024];     // compacted source slot of each output slot
+  __shared__ int s_cnt;
+  __shared__ int wave_cnt[4];
+  const int n = blockIdx.x;
+  const int cnt = min(p.counts[n], p.K);
+  const float sx = p.scale_xy[2 * n], sy = p.scale_xy[2 * n + 1];
+  const float out_h = (float)p.out_hw[2 * n], out_w = (float)p.out_hw[2 * n + 1];
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  // pass 1: per-slot keep decision + new box (written to out_boxes at its compacted position later)
+  for (int base = 0; base < cnt; base += 256) {
+    const int j = base + threadIdx.x;
+    bool keep = false;
+    float b[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j < cnt) {
+      const float* s = p.boxes + ((long)n * p.K + j) * 5;
+      b[0] = s[0]; b[1] = s[1]; b[2] = s[2]; b[3] = s[3]; b[4] = s[4];
+      keep = !p.do_filter_small || (fminf(b[2], b[3]) >= p.min_box_dim);       // filter_small_boxes
+      // RotatedBoxes.scale(sx, sy)
+      b[0] *= sx;
+      b[1] *= sy;
+      const float theta = b[4] * 3.14159265358979323846f / 180.0f;
+      float sn, cs;
+      sincosf(theta, &sn, &cs);
+      b[2] *= sqrtf((sx * cs) * (sx * cs) + (sy * sn) * (sy * sn));
+      b[3] *= sqrtf((sx * sn) * (sx * sn) + (sy * cs) * (sy * cs));
+      b[4] = atan2f(sx * sn, sy * cs) * 180.0f / 3.14159265358979323846f;
+      // RotatedBoxes.clip(out size): normalise angle; clip only |angle| <= 1 deg
+      b[4] = floor_mod_f(b[4] + 180.0f, 360.0f) - 180.0f;
+      if (fabsf(b[4]) <= 1.0f) {
+        float x1 = b[0] - b[2] / 2.0f, y1 = b[1] - b[3] / 2.0f, x2 = b[0] + b[2] / 2.0f, y2 = b[1] + b[3] / 2.0f;
+        x1 = fminf(fmaxf(x1, 0.f), out_w); x2 = fminf(fmaxf(x2, 0.f), out_w);
+        y1 = fminf(fmaxf(y1, 0.f), out_h); y2 = fminf(fmaxf(y2, 0.f), out_h);
+        b[0] = (x1 + x2) / 2.0f;
+        b[1] = (y1 + y2) / 2.0f;
+        b[2] = fminf(b[2], x2 - x1);
+        b[3] = fminf(b[3], y2 - y1);
+      }
+      keep = keep && (b[2] > 0.f) && (b[3] > 0.f);                               // nonempty()
+    }
+    // ordered compaction across the 256 threads (4 wavefronts)
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = s_cnt;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (keep) {
+      const int dst = off + before;
+      keep_src[dst] = j;
+      float* o = p.out_boxes + ((long)n * p.K + dst) * 5;
+      o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3]; o[4] = b[4];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_cnt += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int kept = s_cnt;
+  if (threadIdx.x == 0) p.out_count[n] = kept;
+  for (int d = threadIdx.x; d < kept; d += 256) {
+    const int j = keep_src[d];
+    p.out_scores[(long)n * p.K + d] = p.scores[(long)n * p.K + j];
+    if (p.orient) {
+      p.out_orient[((long)n * p.K + d) * 2] = p.orient[((long)n * p.K + j) * 2];
+      p.out_orient[((long)n * p.K + d) * 2 + 1] = p.orient[((long)n * p.K + j) * 2 + 1];
+    }
+  }
+  if (p.text) {
+    const long r0 = p.roi_start[n];
+    for (int d = 0; d < kept; ++d) {
+      const float* src = p.text + (r0 + keep_src[d]) * (long)p.TC;
+      float* dst = p.out_text + ((long)n * p.K + d) * p.TC;
+      for (int i = threadIdx.x; i < p.TC; i += 256) dst[i] = src[i];
+    }
+  }
+}
+
+extern "C" int glass_detections_finalize(const float* boxes, const float* scores, const float* orient, const float* text,
+                                         const int* counts, const int* roi_start, const float* scale_xy, const int* out_hw,
+                                         int N, int K, int TC, float min_box_dim, int do_filter_small, float* out_boxes,
+                                         float* out_scores, float* out_orient, float* out_text, int* out_count,
+                                         glass_stream_t stream) {
+  if (N == 0) return GLASS_OK;
+  GLASS_CHECK_ARG(K >= 0 && K <= 1024, "glass_detections_finalize: K=%d (max 1024)", K);
+  GLASS_CHECK_ARG(counts && scale_xy && out_hw && out_count, "glass_detections_finalize: null pointer");
+  GLASS_CHECK_ARG(K == 0 || (boxes && scores && out_boxes && out_scores), "glass_detections_finalize: null boxes");
+  GLASS_CHECK_ARG(!orient || out_orient, "glass_detections_finalize: orient without out_orient");
+  GLASS_CHECK_ARG(!text || (out_text && roi_start && TC > 0), "glass_detections_finalize: text without out_text/roi_start");
+  DetParams p;
+  p.boxes = boxes; p.scores = scores; p.orient = orient; p.text = text; p.counts = counts; p.roi_start = roi_start;
+  p.scale_xy = scale_xy; p.out_hw = out_hw; p.N = N; p.K = K; p.TC = TC; p.min_box_dim = min_box_dim;
+  p.do_filter_small = do_filter_small; p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_orient = out_orient;
+  p.out_text = out_text; p.out_count = out_count;
+  hipLaunchKernelGGL(detections_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, p);
+  GLASS_CHECK_LAUNCH("glass_detections_finalize");
+  return GLASS_OK;
+}

@@ -32,6 +32,41 @@ from .fusion_modules import P2P3Fusion, build_hybrid_feature_fusion
 from .local_feature_extraction import build_hybrid_feature_extractor
 
 
+class BatchedDetections:
+    """Padded, device-resident detections of one step: boxes [N,K,5], scores [N,K], orient [N,K,2]|None,
+    counts (device int32 [N] + host list), text [sum counts, T, C]|None with per-image row offsets."""
+
+    def __init__(self, boxes, scores, orient, counts_dev, counts_host, image_sizes):
+        self.boxes, self.scores, self.orient = boxes, scores, orient
+        self.counts_dev, self.counts_host, self.image_sizes = counts_dev, list(counts_host), list(image_sizes)
+        self.text = None
+        self.roi_start_host = [0]
+        for c in self.counts_host[:-1]:
+            self.roi_start_host.append(self.roi_start_host[-1] + c)
+
+    def to_instances(self) -> List[Instances]:
+        """per-image views, no kernels besides one zero-fill for pred_classes"""
+        N, K = self.scores.shape
+        classes = torch.zeros((N, K), dtype=torch.int64, device=self.scores.device)
+        out = []
+        for n, size in enumerate(self.image_sizes):
+            c = self.counts_host[n]
+            r = Instances(size)
+            r.pred_boxes = RotatedBoxes(self.boxes[n, :c])
+            r.scores = self.scores[n, :c]
+            r.pred_classes = classes[n, :c]
+            if self.orient is not None:
+                r.orientations = self.orient[n, :c]
+            if self.text is not None:
+                if self.text.dim() == 4:                      # padded [N,K,T,C] (after the finalize kernel)
+                    r.pred_text_prob = self.text[n, :c]
+                else:
+                    s0 = self.roi_start_host[n]
+                    r.pred_text_prob = self.text[s0:s0 + c]
+            out.append(r)
+        return out
+
+
 def images_nhwc4(images: ImageList) -> torch.Tensor:
     """NHWC4 batch behind an ImageList (ours carry it; a foreign one is converted once)."""
     t = getattr(images, "nhwc4", None)
@@ -126,24 +161,43 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
 
     def forward_batched(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor,
                         prop_counts: torch.Tensor, image_sizes: List[Tuple[int, int]],
-                        override_boxes: Optional[List[torch.Tensor]] = None) -> List[Instances]:
+                        override_boxes: Optional[List[torch.Tensor]] = None) -> BatchedDetections:
         device = prop_boxes.device
         hw = torch.tensor(image_sizes, dtype=torch.int32, device=device)
         ob, os_, oi, orient2, oc = self.box_branch_batched(feats, prop_boxes, prop_counts, hw)
-        # the one host sync of the step: per-image detection counts
-        results, _ = self.box_predictor.to_instances(ob, os_, oi, orient2, oc, image_sizes)
+        orient = None
+        if orient2 is not None:
+            orient = torch.gather(orient2, 1, oi.long().unsqueeze(-1).expand(-1, -1, 2))
+        counts = oc.cpu().tolist()           # the one host sync of the step: per-image detection counts
+        det = BatchedDetections(ob, os_, orient, oc, counts, image_sizes)
         if override_boxes is not None:
             # synthetic-workload hook (bench / teacher-forced parity): recognise these boxes instead
-            results = []
-            for b, image_size in zip(override_boxes, image_sizes):
-                r = Instances(image_size)
-                r.pred_boxes = RotatedBoxes(b.to(device).float().contiguous())
-                r.scores = torch.ones((len(b),), dtype=torch.float32, device=device)
-                r.pred_classes = torch.zeros((len(b),), dtype=torch.int64, device=device)
-                if self.box_predictor.orientation_on:
-                    r.orientations = torch.zeros((len(b), 2), dtype=torch.float32, device=device)
-                results.append(r)
-        return self._recognize_into(img_nhwc4, feats, results)
+            N = len(override_boxes)
+            counts = [len(b) for b in override_boxes]
+            K = max(counts + [1])
+            pb = torch.zeros((N, K, 5), dtype=torch.float32, device=device)
+            for n, b in enumerate(override_boxes):
+                if len(b):
+                    pb[n, : len(b)] = b.to(device).float()
+            sc = torch.zeros((N, K), dtype=torch.float32, device=device)
+            for n, c in enumerate(counts):
+                sc[n, :c] = 1.0
+            det = BatchedDetections(pb, sc, torch.zeros((N, K, 2), device=device) if orient2 is not None else None,
+                                    torch.tensor(counts, dtype=torch.int32, device=device), counts, image_sizes)
+        return self.recognize_batched(img_nhwc4, feats, det)
+
+    def recognize_batched(self, img_nhwc4, feats, det: BatchedDetections) -> BatchedDetections:
+        if not self.recognizer_on:
+            return det
+        counts = det.counts_host
+        R = sum(counts)
+        if R == 0:
+            return det          # reference: recognizer_head returns the instances untouched (recognizer_head_v2.py:151)
+        device = img_nhwc4.device
+        boxes = torch.cat([det.boxes[n, :c] for n, c in enumerate(counts)], 0).contiguous()
+        roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
+        det.text = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts))
+        return det
 
     def _recognize_into(self, img_nhwc4, feats, results: List[Instances]) -> List[Instances]:
         if not self.recognizer_on:

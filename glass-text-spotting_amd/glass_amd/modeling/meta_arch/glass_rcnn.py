@@ -44,6 +44,7 @@ class GeneralizedRCNN(InferenceModule):
         self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
         self.input_format = cfg.INPUT.FORMAT
         self._loaded = False
+        self.last_batch = None      # padded device-resident results of the last step (for distributed.pack_padded)
 
     @property
     def device(self) -> torch.device:
@@ -94,14 +95,45 @@ class GeneralizedRCNN(InferenceModule):
                 hw = torch.tensor(images.image_sizes, dtype=torch.int32, device=self._device)
                 rpn_in = [feats[f] for f in self.proposal_generator.in_features]
                 pboxes, _plogits, pcounts = self.proposal_generator.forward_batched(rpn_in, hw)
-                results = self.roi_heads.forward_batched(images.nhwc4, feats, pboxes, pcounts, images.image_sizes,
-                                                         override_boxes=override_boxes)
-            else:
-                detected_instances = [x.to(self._device) for x in detected_instances]
-                results = self.roi_heads._recognize_into(images.nhwc4, feats, detected_instances)
+                det = self.roi_heads.forward_batched(images.nhwc4, feats, pboxes, pcounts, images.image_sizes,
+                                                     override_boxes=override_boxes)
+                if do_postprocess:
+                    return self._postprocess_batched(det, batched_inputs, images.image_sizes)
+                self.last_batch = det
+                return det.to_instances()
+            detected_instances = [x.to(self._device) for x in detected_instances]
+            results = self.roi_heads._recognize_into(images.nhwc4, feats, detected_instances)
             if do_postprocess:
                 return self._postprocess(results, batched_inputs, images.image_sizes)
             return results
+
+    # small-box filter of GlassRCNN._postprocess; the stock d2 GeneralizedRCNN has none
+    _filter_small = False
+    _min_box_dim = 0.0
+
+    def _postprocess_batched(self, det, batched_inputs, image_sizes):
+        """`_postprocess` for the whole step in one kernel (ops.native.detections_finalize) + one read of
+        the N surviving counts; per-image Instances are views of the padded outputs."""
+        from ..fusion.recognizers_hybrid_head import BatchedDetections
+        N = len(image_sizes)
+        sxy, ohw, out_sizes = [], [], []
+        for inp, image_size in zip(batched_inputs, image_sizes):
+            height = inp.get("height", image_size[0])
+            width = inp.get("width", image_size[1])
+            sxy.append([float(width) / image_size[1], float(height) / image_size[0]])
+            ohw.append([int(height), int(width)])
+            out_sizes.append((height, width))
+        dev = self._device
+        scale_xy = torch.tensor(sxy, dtype=torch.float32).to(dev)
+        out_hw = torch.tensor(ohw, dtype=torch.int32).to(dev)
+        roi_start = torch.tensor(det.roi_start_host, dtype=torch.int32).to(dev) if det.text is not None else None
+        ob, os_, oo, ot, oc = K.detections_finalize(det.boxes, det.scores, det.orient, det.text, det.counts_dev, roi_start,
+                                                    scale_xy, out_hw, float(self._min_box_dim), self._filter_small)
+        counts = oc.cpu().tolist()
+        post = BatchedDetections(ob, os_, oo, oc, counts, out_sizes)
+        post.text = ot
+        self.last_batch = post
+        return [{"instances": r} for r in post.to_instances()]
 
     def _postprocess(self, instances, batched_inputs, image_sizes):
         out = []
@@ -126,6 +158,8 @@ class GlassRCNN(GeneralizedRCNN):
         self.valid_score = cfg.INFERENCE_TH_TEST if hasattr(cfg, "INFERENCE_TH_TEST") else 0
         if self.inflate_ratio or self.drop_overlapping_boxes:
             raise NotImplementedError("INFLATE_RATIO / DROP_OVERLAPPING (eval-CLI only keys) are not built")
+        self._filter_small = bool(self.filter_small_boxes)
+        self._min_box_dim = float(self.post_processor.min_box_dim)
 
     def _postprocess(self, instances, batched_inputs, image_sizes):
         out = []

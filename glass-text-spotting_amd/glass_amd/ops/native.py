@@ -303,3 +303,25 @@ def attention_decode(x: torch.Tensor, xproj: torch.Tensor, weights: dict, roi_im
                                        c_void_p(_dev(out)), c_void_p(_dev(pred)), c_void_p(stream_handle())),
           "glass_attention_decode")
     return out
+
+
+def detections_finalize(boxes: torch.Tensor, scores: torch.Tensor, orient: Optional[torch.Tensor],
+                        text: Optional[torch.Tensor], counts: torch.Tensor, roi_start: Optional[torch.Tensor],
+                        scale_xy: torch.Tensor, out_hw: torch.Tensor, min_box_dim: float, do_filter_small: bool):
+    """Batched meta-arch postprocess. boxes [N,K,5] ... -> (boxes, scores, orient|None, text|None, counts) padded."""
+    N, K, _ = boxes.shape
+    dev = boxes.device
+    ob = torch.zeros((N, K, 5), dtype=torch.float32, device=dev)
+    os_ = torch.zeros((N, K), dtype=torch.float32, device=dev)
+    oo = torch.zeros((N, K, 2), dtype=torch.float32, device=dev) if orient is not None else None
+    TC = int(text.shape[1] * text.shape[2]) if text is not None else 0
+    ot = torch.zeros((N, K) + tuple(text.shape[1:]), dtype=torch.float32, device=dev) if text is not None else None
+    oc = torch.zeros((N,), dtype=torch.int32, device=dev)
+    _f32c(boxes, "boxes"); _f32c(scores, "scores"); _i32(counts, "counts"); _f32c(scale_xy, "scale_xy"); _i32(out_hw, "out_hw")
+    opt = lambda t: c_void_p(_dev(t)) if t is not None else c_void_p(None)
+    check(lib().glass_detections_finalize(
+        c_void_p(_dev(boxes)), c_void_p(_dev(scores)), opt(orient), opt(text), c_void_p(_dev(counts)), opt(roi_start),
+        c_void_p(_dev(scale_xy)), c_void_p(_dev(out_hw)), N, K, TC, c_float(min_box_dim), int(bool(do_filter_small)),
+        c_void_p(_dev(ob)), c_void_p(_dev(os_)), opt(oo), opt(ot), c_void_p(_dev(oc)), c_void_p(stream_handle())),
+        "glass_detections_finalize")
+    return ob, os_, oo, ot, oc

@@ -143,6 +143,19 @@ int glass_box_decode(const float* cls_logits, const float* deltas, const float* 
                      int R, const float* weights5_host, float* out_boxes, float* out_fg_prob, float* out_orient2,
                      glass_stream_t stream);
 
+/* Batched GlassRCNN._postprocess (glass/modeling/meta_arch/glass_rcnn.py:103-128) for all N images of a
+ * step: filter_small_boxes (min(w,h) >= min_box_dim, if do_filter_small; post_processor_rotated_boxes.py:
+ * 89-94) then detector_postprocess (post_processor_academic.py:118-178): RotatedBoxes.scale(sx,sy),
+ * clip to the output size, drop empty boxes [d2-recall for scale/clip] — with ordered compaction of every
+ * per-detection field.  boxes [N,K,5], scores [N,K], orient [N,K,2] or NULL, counts [N] device ints
+ * (slots used), text [sum R, TC] with image n's rows starting at roi_start[n] (NULL: no text),
+ * scale_xy [N,2] device floats (sx,sy), out_hw [N,2] device ints (h,w).  Outputs are padded [N,K,...]
+ * tensors with out_count[n] valid leading rows.  K <= 1024.                                      */
+int glass_detections_finalize(const float* boxes, const float* scores, const float* orient, const float* text,
+                              const int* counts, const int* roi_start, const float* scale_xy, const int* out_hw, int N,
+                              int K, int TC, float min_box_dim, int do_filter_small, float* out_boxes, float* out_scores,
+                              float* out_orient, float* out_text, int* out_count, glass_stream_t stream);
+
 /* pairwise rotated IoU matrix out[n1][n2] (d2 pairwise_iou_rotated; glass/structures/boxes.py:33,
  * used by the post-processor's pairwise_ioa_rotated).                                     */
 int glass_pairwise_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2, float* out,
