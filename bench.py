@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--side", type=int, default=SIDE)
     ap.add_argument("--rois", type=int, default=ROIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="e2e", choices=["e2e", "backbone"],
+                    help="e2e = BASELINE configs[2] (default, the metric's config); backbone = configs[1] (ResNet50-FPN only)")
     ap.add_argument("--cpu-side", type=int, default=SIDE, help="image side of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -141,7 +143,13 @@ def main():
     max_det = cfg.TEST.DETECTIONS_PER_IMAGE
     steps_txt = cfg.MODEL.ROI_RECOGNIZER_HEAD.MAX_WORD_LENGTH + 1
 
+    if args.workload == "backbone":
+        il = model.preprocess_image(inputs)
+
     def local_step():
+        if args.workload == "backbone":                           # BASELINE configs[1]: trunk + FPN only
+            model.backbone.forward_nhwc(il.nhwc4)
+            return torch.zeros((B, 1), device=dev)
         model.inference(inputs, override_boxes=boxes)            # list[{"instances": Instances}] (views) ...
         return pack_padded(model.last_batch, max_det, steps_txt)  # ... + the padded batch for the gather
 
@@ -195,8 +203,10 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: backbone + RotatedROIAlign + recognition head, "
-                                   f"{args.rois} RoIs/img, bs={B}/GPU, {args.side}x{args.side} (padded to /32), fp32",
+            "config": {"workload": ("BASELINE.json configs[2]: backbone + RotatedROIAlign + recognition head, "
+                                    f"{args.rois} RoIs/img, bs={B}/GPU, {args.side}x{args.side} (padded to /32), fp32")
+                       if args.workload == "e2e" else
+                       f"BASELINE.json configs[1]: ResNet50-FPN backbone only, bs={B}/GPU, {args.side}x{args.side}, fp32",
                        "images_per_gpu_per_step": B, "rois_per_image": args.rois, "proposals_per_image": 100,
                        "weights": "random-init (seed 1234), reference architecture",
                        "parallelism": f"image-shard x{world}, 1 all_gather of result records/step"},

@@ -1,0 +1,81 @@
+"""GPU: the BASELINE.json configurations as parity / stress cases.
+configs[0] 512x512, pretrain-style cfg (stock GeneralizedRCNN) vs the CPU oracle end to end;
+configs[1] backbone+FPN at 1000x1000 (padded 1024^2) vs the CPU oracle (full size, B=1);
+configs[4] TextOCR-style stress shape (1333 long side, 100 RoIs/img, B=8, orientation head off), fp32:
+           runs, finite, well-formed (the fp16 storage variant of that config is not built)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(opts=()):
+    from glass_amd.config import get_glass_cfg
+    return get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", "cuda:0"] + list(opts))
+
+
+@pytest.fixture(scope="module")
+def sd():
+    from glass_amd.utils.synth import make_state_dict
+    return make_state_dict(1234)
+
+
+def test_config0_512_pretrain_style_end_to_end_vs_oracle(sd):
+    import glass_amd
+    from glass_amd.utils.synth import make_image
+    from oracle import glass_cpu as O
+    cfg = _cfg(["MODEL.META_ARCHITECTURE", "GeneralizedRCNN"])
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd)
+    img = make_image(20, 512, 512).permute(2, 0, 1).float()
+    out = m.inference([{"image": img.cuda()}], do_postprocess=False)[0]
+    ref = O.glass_inference(sd, [img], cfg)[0]
+    assert len(out) == len(ref["scores"]) and len(out) > 0
+    np.testing.assert_allclose(out.scores.cpu().numpy(), ref["scores"].numpy(), atol=1e-3)
+    np.testing.assert_allclose(out.pred_boxes.tensor.cpu().numpy(), ref["pred_boxes"].numpy(), rtol=1e-4, atol=1e-2)
+    p, q = out.pred_text_prob.cpu().numpy(), ref["pred_text_prob"].numpy()
+    assert np.abs(p - q).max() < 5e-3 and (p.argmax(-1) == q.argmax(-1)).mean() > 0.99
+
+
+def test_config1_backbone_fpn_full_size_vs_oracle(sd):
+    import glass_amd
+    from glass_amd.utils.synth import make_image
+    from oracle import glass_cpu as O
+    cfg = _cfg()
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd)
+    img = make_image(21, 1000, 1000).permute(2, 0, 1).float()
+    il = m.preprocess_image([{"image": img.cuda()}])
+    assert tuple(il.nhwc4.shape) == (1, 1024, 1024, 4)
+    feats = m.backbone.forward_nhwc(il.nhwc4)
+    x, _ = O.preprocess([img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+    ref = O.resnet50_fpn(sd, x)
+    for k, r in ref.items():
+        got = feats[k].permute(0, 3, 1, 2).cpu()
+        assert got.shape == r.shape
+        scale = max(1.0, float(r.abs().max()))
+        assert float((got - r).abs().max()) < 1e-3 * scale, k
+
+
+def test_config4_textocr_stress_shape_runs(sd):
+    import glass_amd
+    from glass_amd.utils.synth import make_boxes, make_image
+    cfg = _cfg(["MODEL.ORIENTATION_ON", False])
+    sd2 = {k: v for k, v in sd.items() if "orientation_pred" not in k}
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd2)
+    B, H, W, R = 8, 1000, 1333, 100
+    inputs = [{"image": make_image(30 + i, H, W).permute(2, 0, 1).float().contiguous().cuda()} for i in range(B)]
+    boxes = [make_boxes(30 + i, R, H, W).cuda() for i in range(B)]
+    out = m.inference(inputs, override_boxes=boxes)
+    assert len(out) == B
+    for o in out:
+        inst = o["instances"]
+        assert inst.image_size == (H, W) and 0 < len(inst) <= R
+        assert torch.isfinite(inst.pred_text_prob).all() and inst.pred_text_prob.shape[1:] == (26, 97)
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() < 200 * 2 ** 30
