@@ -20,6 +20,8 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp/rcp (|err| < 2e-7 absolute; saturates cleanly)
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
 
 // acc[g][r] += sum_k W[g*gstride + u][k] * vec[r][k] for one output unit `u` per thread, weights in the
 // k-blocked layout (w4[k4 * rows_total + row] = 4 consecutive k of `row`).  L2 latency (~300 ns) is far
@@ -191,60 +193,130 @@ extern "C" int glass_gc_attention_inplace(float* x, int R, int HW, int C, int he
 }
 
 // ================================================================== BiLSTM recurrence
-// grid = (ceil(R/RB), 2 directions); 256 threads, thread u owns hidden unit u: its i,f,g,o rows
-// (u, 256+u, 512+u, 768+u of W_hh) and the cell state of every RoI of the group in registers.
+// One launch per time step (T launches per layer, issued back to back by the host function).  A persistent
+// workgroup per RoI group would have to stream the whole 1 MiB recurrent matrix through ONE CU every step
+// (~40 GB/s per CU -> 27 us/step); instead each step is spread over the chip: grid = (RoI groups of 16,
+// 8 blocks of 32 hidden units, 2 directions), every workgroup streams only its 128 KiB weight slice
+// (4 gates x 32 units x 256) from L2 and keeps the 16 previous hidden rows in LDS.  The hidden/cell state
+// lives in a small global workspace, double-buffered across launches (stream order is the barrier).
 constexpr int LSTM_HD = 256;
-constexpr int LSTM_RB = 8;
+constexpr int LS_RB = 16;   // RoIs per workgroup (= the N of a 16x16x4 MFMA)
+constexpr int LS_UB = 32;   // hidden units per workgroup
 
-__global__ __launch_bounds__(256) void bilstm_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
-                                                     float* __restrict__ out, int R, int T) {
-  __shared__ __attribute__((aligned(16))) float h[LSTM_RB][LSTM_HD];
-  const int u = threadIdx.x;
-  const int dir = blockIdx.y;
-  const int r0 = blockIdx.x * LSTM_RB;
-  const int nr = min(LSTM_RB, R - r0);
-  const float4* w = reinterpret_cast<const float4*>(whh) + (long)dir * (LSTM_HD / 4) * (4 * LSTM_HD);
-  float c[LSTM_RB];
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// C[16 rows][16 RoIs] += W[row0 .. row0+16)[0..K) . hs[roi][0..K)^T on v_mfma_f32_16x16x4_f32.
+// W is the plain row-major [rows][K] matrix (nn.LSTM / nn.GRU layout).  Lane l = (row r = l&15,
+// k-quarter q = l>>4) loads 16 bytes = W[row0+r][16S + 4q .. +3] and hs[l&15][16S + 4q .. +3]; MFMA c of
+// super-step S then contracts k = 16S + 4q + c on both operands, so the 16 k of a super-step are all
+// covered once (the order inside the fp32 sum differs from k-ascending, nothing else).
+template <int K>
+__device__ __forceinline__ void mfma_rows16(const float* __restrict__ W, int ldw, int row0, const float* hs, int ldh,
+                                            int lane, f32x4& acc) {
+  const float* wp = W + (long)(row0 + (lane & 15)) * ldw + (lane >> 4) * 4;
+  const float* hp = hs + (lane & 15) * ldh + (lane >> 4) * 4;
+  // all K/16 weight loads of the job are issued before the first MFMA (one L2 round trip per job, not per
+  // super-step); two accumulators halve the dependent-MFMA chain
+  float4 a[K / 16];
 #pragma unroll
-  for (int r = 0; r < LSTM_RB; ++r) { c[r] = 0.f; h[r][u] = 0.f; }
+  for (int S = 0; S < K / 16; ++S) a[S] = *reinterpret_cast<const float4*>(wp + S * 16);
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int S = 0; S < K / 16; ++S) {
+    const float4 b = *reinterpret_cast<const float4*>(hp + S * 16);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S].x, b.x, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S].y, b.y, acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S].z, b.z, acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S].w, b.w, acc2, 0, 0, 0);
+  }
+  acc += acc2;
+}
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ xg, const float* __restrict__ whh,
+                                                        const float* __restrict__ h_prev, float* __restrict__ h_next,
+                                                        float* __restrict__ c_state, float* __restrict__ out, int R, int T,
+                                                        int step) {
+  __shared__ __attribute__((aligned(16))) float hs[LS_RB][LSTM_HD + 4];   // +4: 16-byte row skew against bank conflicts
+  __shared__ float gates[LS_RB][4 * LS_UB + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dir = blockIdx.z, ub = blockIdx.y, r0 = blockIdx.x * LS_RB;
+  const int t = dir == 0 ? step : T - 1 - step;
+  const int nr = min(LS_RB, R - r0);
+  for (int i = tid; i < LS_RB * (LSTM_HD / 4); i += 256) {
+    const int r = i / (LSTM_HD / 4), k4 = i % (LSTM_HD / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nr) v = reinterpret_cast<const float4*>(h_prev + ((long)(r0 + r) * 2 + dir) * LSTM_HD)[k4];
+    *reinterpret_cast<float4*>(&hs[r][k4 * 4]) = v;
+  }
   __syncthreads();
-  for (int step = 0; step < T; ++step) {
-    const int t = dir == 0 ? step : T - 1 - step;
-    float acc[4][LSTM_RB];
+  // the workgroup's 128 gate rows = 8 row tiles of 16: tile = gate * 2 + half-of-32-units; 2 tiles per wavefront
+  const float* W = whh + (long)dir * (4 * LSTM_HD) * LSTM_HD;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+  for (int q = 0; q < 2; ++q) {
+    const int tile = wave * 2 + q;
+    const int g = tile >> 1, uh = tile & 1;
+    const int row0 = g * LSTM_HD + ub * LS_UB + uh * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    mfma_rows16<LSTM_HD>(W, LSTM_HD, row0, &hs[0][0], LSTM_HD + 4, lane, acc);
+    // C layout: col = lane & 15 (RoI), row = (lane >> 4) * 4 + e
 #pragma unroll
-      for (int r = 0; r < LSTM_RB; ++r)
-        acc[g][r] = (r < nr) ? xg[(((long)(r0 + r) * T + t) * 2 + dir) * (4 * LSTM_HD) + g * LSTM_HD + u] : 0.f;
-    stream_matvec<4, LSTM_RB, 4>(w, 4 * LSTM_HD, LSTM_HD, u, LSTM_HD / 4, &h[0][0], LSTM_HD, acc);
-    __syncthreads();   // everyone has finished reading h of the previous step
-#pragma unroll
-    for (int r = 0; r < LSTM_RB; ++r) {
-      const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]), gg = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
-      c[r] = fg * c[r] + ig * gg;
-      const float hn = og * tanhf(c[r]);
-      h[r][u] = hn;
-      if (r < nr) out[((long)(r0 + r) * T + t) * (2 * LSTM_HD) + dir * LSTM_HD + u] = hn;
+    for (int e = 0; e < 4; ++e) gates[lane & 15][g * LS_UB + uh * 16 + (lane >> 4) * 4 + e] = acc[e];
+  }
+  __syncthreads();
+  for (int i = tid; i < LS_RB * LS_UB; i += 256) {
+    const int r = i / LS_UB, ul = i % LS_UB;
+    if (r < nr) {
+      const int u = ub * LS_UB + ul;
+      const long idx = ((long)(r0 + r) * 2 + dir) * LSTM_HD + u;
+      const float* xr = xg + (((long)(r0 + r) * T + t) * 2 + dir) * (4 * LSTM_HD) + u;
+      const float ig = sigmoidf_(xr[0] + gates[r][ul]), fg = sigmoidf_(xr[LSTM_HD] + gates[r][LS_UB + ul]);
+      const float gg = tanhf(xr[2 * LSTM_HD] + gates[r][2 * LS_UB + ul]), og = sigmoidf_(xr[3 * LSTM_HD] + gates[r][3 * LS_UB + ul]);
+      const float c = fg * c_state[idx] + ig * gg;
+      c_state[idx] = c;
+      const float hn = og * tanhf(c);
+      h_next[idx] = hn;
+      out[((long)(r0 + r) * T + t) * (2 * LSTM_HD) + dir * LSTM_HD + u] = hn;
     }
-    __syncthreads();
   }
 }
 
+extern "C" int64_t glass_bilstm_workspace_bytes(int R, int Hd) { return (int64_t)3 * R * 2 * Hd * sizeof(float); }
+
 extern "C" int glass_bilstm_recurrence(const float* xg, const float* w_hh_packed, float* out, int R, int T, int Hd,
-                                       glass_stream_t stream) {
+                                       void* workspace, int64_t workspace_bytes, glass_stream_t stream) {
   GLASS_CHECK_ARG(Hd == LSTM_HD, "glass_bilstm_recurrence: only Hd=256 is built (got %d)", Hd);
   if (R == 0) return GLASS_OK;
-  GLASS_CHECK_ARG(xg && w_hh_packed && out && T > 0, "glass_bilstm_recurrence: bad args");
-  hipLaunchKernelGGL(bilstm_kernel, dim3(cdiv(R, LSTM_RB), 2), dim3(256), 0, (hipStream_t)stream, xg, w_hh_packed, out, R, T);
+  GLASS_CHECK_ARG(xg && w_hh_packed && out && T > 0 && workspace, "glass_bilstm_recurrence: bad args");
+  GLASS_CHECK_ARG(workspace_bytes >= glass_bilstm_workspace_bytes(R, Hd), "glass_bilstm_recurrence: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)R * 2 * Hd;
+  float* hbuf[2] = {static_cast<float*>(workspace), static_cast<float*>(workspace) + n};
+  float* c = static_cast<float*>(workspace) + 2 * n;
+  hipError_t e = hipMemsetAsync(workspace, 0, 3 * n * sizeof(float), s);     // h0 = c0 = 0
+  if (e != hipSuccess) { glass_set_error("glass_bilstm_recurrence: memset: %s", hipGetErrorString(e)); return GLASS_EHIP; }
+  const dim3 grid(cdiv(R, LS_RB), LSTM_HD / LS_UB, 2);
+  for (int step = 0; step < T; ++step)
+    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, xg, w_hh_packed, hbuf[step & 1], hbuf[(step + 1) & 1], c, out,
+                       R, T, step);
   GLASS_CHECK_LAUNCH("glass_bilstm_recurrence");
   return GLASS_OK;
 }
 
 // ================================================================== attention GRU decoder
+// Two launches per decoding step, issued back to back by the host function (no host sync, argmax feedback
+// stays on device):
+//   dec_fc_att_kernel  (4 RoIs per workgroup): [fc + softmax + argmax of the state h_i -> out[:, i], y_i]
+//                       then [additive attention with h_i -> context, embedding(y_i)] -> inp_{i+1}
+//   dec_gru_kernel     (16 RoIs x 32 hidden units per workgroup): GRU cell on v_mfma_f32_16x16x4_f32,
+//                       every workgroup streams only its 96-row slice of W_ih / W_hh from L2.
+// A persistent workgroup per RoI group has to pull all 2.6 MB of decoder weights through ONE CU per step
+// (80 us/step measured); spreading each step over the chip costs two launch boundaries (~2 us each).
 constexpr int DEC_D = 256;
 constexpr int DEC_RB = 4;
 constexpr int DEC_TMAX = 64;
 constexpr int DEC_CMAX = 256;
+constexpr int GRU_RB = 16;
+constexpr int GRU_UB = 32;
 
 struct DecParams {
   const float* x; const float* xproj;
@@ -253,104 +325,35 @@ struct DecParams {
   int R, T, C, max_len;
   float* out;
   int* pred;
+  float* h0; float* h1; float* inp; int* yprev;     // workspace: state (double-buffered), [emb|ctx], last argmax
 };
 
-__global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
-  __shared__ __attribute__((aligned(16))) float h[DEC_RB][DEC_D];        // GRU state
-  __shared__ __attribute__((aligned(16))) float inp[DEC_RB][2 * DEC_D];  // [embedding | context]
+// step < 0: only the attention part (initial state h = 0, y = 0); do_att == 0: only the fc part (last step)
+__global__ __launch_bounds__(256) void dec_fc_att_kernel(DecParams p, const float* __restrict__ hcur, int step, int do_att) {
+  __shared__ __attribute__((aligned(16))) float h[DEC_RB][DEC_D];
   __shared__ float sproj[DEC_RB][DEC_D];
   __shared__ float energy[DEC_RB][DEC_TMAX];
   __shared__ float logit[DEC_RB][DEC_CMAX];
-  __shared__ int yprev[DEC_RB];
+  __shared__ int ycur[DEC_RB];
   const int u = threadIdx.x, lane = u & 63, wave = u >> 6;
   const int r0 = blockIdx.x * DEC_RB;
   const int nr = min(DEC_RB, p.R - r0);
   const int T = p.T, C = p.C;
-  const float4* sW4 = reinterpret_cast<const float4*>(p.sW);
-  const float4* wih4 = reinterpret_cast<const float4*>(p.w_ih);
-  const float4* whh4 = reinterpret_cast<const float4*>(p.w_hh);
-  const float4* fc4 = reinterpret_cast<const float4*>(p.fcW);
 #pragma unroll
-  for (int r = 0; r < DEC_RB; ++r) h[r][u] = 0.f;
-  if (u < DEC_RB) yprev[u] = 0;
+  for (int r = 0; r < DEC_RB; ++r) h[r][u] = (r < nr) ? hcur[(long)(r0 + r) * DEC_D + u] : 0.f;
+  if (u < DEC_RB) ycur[u] = (step < 0 || u >= nr) ? 0 : p.yprev[r0 + u];
   __syncthreads();
-
-  for (int step = 0; step < p.max_len; ++step) {
-    // ---- 1. sProj = sEmbed(h)
-    {
-      float acc[1][DEC_RB];
-#pragma unroll
-      for (int r = 0; r < DEC_RB; ++r) acc[0][r] = p.sB[u];
-      stream_matvec<1, DEC_RB, 4>(sW4, DEC_D, 0, u, DEC_D / 4, &h[0][0], DEC_D, acc);
-#pragma unroll
-      for (int r = 0; r < DEC_RB; ++r) sproj[r][u] = acc[0][r];
-    }
-    __syncthreads();
-    // ---- 2. energies e[r][t] = wEmbed(tanh(sProj + xProj[t])): wavefront per (r,t), lanes over D
-    {
-      const float4 ww = *reinterpret_cast<const float4*>(p.wW + lane * 4);
-      const float wb = p.wB[0];
-      for (int pr = wave; pr < nr * T; pr += 4) {
-        const int r = pr / T, t = pr - r * T;
-        const float4 xp = *reinterpret_cast<const float4*>(p.xproj + ((long)(r0 + r) * T + t) * DEC_D + lane * 4);
-        const float4 sp = *reinterpret_cast<const float4*>(&sproj[r][lane * 4]);
-        float s = ww.x * tanhf(sp.x + xp.x) + ww.y * tanhf(sp.y + xp.y) + ww.z * tanhf(sp.z + xp.z) + ww.w * tanhf(sp.w + xp.w);
-        s = wave_sum(s);
-        if (lane == 0) energy[r][t] = s + wb;
-      }
-    }
-    __syncthreads();
-    // ---- 3. softmax over t (one wavefront per RoI), 4. embedding lookup
-    if (wave < nr) {
-      const int r = wave;
-      const float v = lane < T ? energy[r][lane] : -INFINITY;
-      const float m = wave_max(v);
-      const float e = lane < T ? expf(v - m) : 0.f;
-      const float s = wave_sum(e);
-      if (lane < T) energy[r][lane] = e / s;
-    }
-#pragma unroll
-    for (int r = 0; r < DEC_RB; ++r) inp[r][u] = (r < nr) ? p.emb[(long)yprev[r] * DEC_D + u] : 0.f;
-    __syncthreads();
-    // ---- 4. context = alpha . x  (thread per feature)
-#pragma unroll
-    for (int r = 0; r < DEC_RB; ++r) {
-      float s = 0.f;
-      if (r < nr)
-        for (int t = 0; t < T; ++t) s += energy[r][t] * p.x[((long)(r0 + r) * T + t) * DEC_D + u];
-      inp[r][DEC_D + u] = s;
-    }
-    __syncthreads();
-    // ---- 5. GRU cell: thread u owns hidden unit u (rows u, D+u, 2D+u = r,z,n gates)
-    {
-      float gi[3][DEC_RB], gh[3][DEC_RB];
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int r = 0; r < DEC_RB; ++r) { gi[g][r] = p.b_ih[g * DEC_D + u]; gh[g][r] = p.b_hh[g * DEC_D + u]; }
-      stream_matvec<3, DEC_RB, 4>(wih4, 3 * DEC_D, DEC_D, u, 2 * DEC_D / 4, &inp[0][0], 2 * DEC_D, gi);
-      stream_matvec<3, DEC_RB, 4>(whh4, 3 * DEC_D, DEC_D, u, DEC_D / 4, &h[0][0], DEC_D, gh);
-      __syncthreads();   // all reads of the old state are done
-#pragma unroll
-      for (int r = 0; r < DEC_RB; ++r) {
-        const float rg = sigmoidf_(gi[0][r] + gh[0][r]);
-        const float zg = sigmoidf_(gi[1][r] + gh[1][r]);
-        const float ng = tanhf(gi[2][r] + rg * gh[2][r]);
-        h[r][u] = (1.f - zg) * ng + zg * h[r][u];
-      }
-    }
-    __syncthreads();
-    // ---- 6. logits = fc(h) * temperature
+  if (step >= 0) {
+    // ---- logits = fc(h) * temperature; softmax over C; argmax (first maximum)
     if (u < C) {
       float acc[1][DEC_RB];
 #pragma unroll
       for (int r = 0; r < DEC_RB; ++r) acc[0][r] = p.fcB[u];
-      stream_matvec<1, DEC_RB, 4>(fc4, C, 0, u, DEC_D / 4, &h[0][0], DEC_D, acc);
+      stream_matvec<1, DEC_RB, 16>(reinterpret_cast<const float4*>(p.fcW), C, 0, u, DEC_D / 4, &h[0][0], DEC_D, acc);
 #pragma unroll
       for (int r = 0; r < DEC_RB; ++r) logit[r][u] = acc[0][r] * p.temperature;
     }
     __syncthreads();
-    // ---- 7. softmax over C classes + argmax (first maximum), one wavefront per RoI
     if (wave < nr) {
       const int r = wave;
       float v[DEC_CMAX / 64];
@@ -385,11 +388,128 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecParams p) {
         if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
       }
       if (lane == 0) {
-        yprev[r] = besti;
+        ycur[r] = besti;
+        p.yprev[r0 + r] = besti;
         p.pred[(long)(r0 + r) * p.max_len + step] = besti;
       }
     }
     __syncthreads();
+  }
+  if (!do_att) return;
+  // ---- sProj = sEmbed(h)
+  {
+    float acc[1][DEC_RB];
+#pragma unroll
+    for (int r = 0; r < DEC_RB; ++r) acc[0][r] = p.sB[u];
+    stream_matvec<1, DEC_RB, 16>(reinterpret_cast<const float4*>(p.sW), DEC_D, 0, u, DEC_D / 4, &h[0][0], DEC_D, acc);
+#pragma unroll
+    for (int r = 0; r < DEC_RB; ++r) sproj[r][u] = acc[0][r];
+  }
+  __syncthreads();
+  // ---- energies e[r][t] = wEmbed(tanh(sProj + xProj[t])): wavefront per (r,t), lanes over D
+  {
+    const float4 ww = *reinterpret_cast<const float4*>(p.wW + lane * 4);
+    const float wb = p.wB[0];
+    const int npairs = nr * T;
+    for (int base = wave; base < npairs; base += 4 * 8) {
+      float4 xp[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pr = min(base + 4 * i, npairs - 1);
+        const int r = pr / T, t = pr - r * T;
+        xp[i] = *reinterpret_cast<const float4*>(p.xproj + ((long)(r0 + r) * T + t) * DEC_D + lane * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pr = base + 4 * i;
+        if (pr < npairs) {
+          const int r = pr / T, t = pr - r * T;
+          const float4 sp = *reinterpret_cast<const float4*>(&sproj[r][lane * 4]);
+          float s = ww.x * tanh_fast(sp.x + xp[i].x) + ww.y * tanh_fast(sp.y + xp[i].y) + ww.z * tanh_fast(sp.z + xp[i].z) +
+                    ww.w * tanh_fast(sp.w + xp[i].w);
+          s = wave_sum(s);
+          if (lane == 0) energy[r][t] = s + wb;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < nr) {
+    const int r = wave;
+    const float v = lane < T ? energy[r][lane] : -INFINITY;
+    const float m = wave_max(v);
+    const float e = lane < T ? expf(v - m) : 0.f;
+    const float s = wave_sum(e);
+    if (lane < T) energy[r][lane] = e / s;
+  }
+  __syncthreads();
+  // ---- inp = [embedding(y) | context = alpha . x]
+  for (int r = 0; r < nr; ++r) {
+    float s = 0.f;
+    const float* xr = p.x + (long)(r0 + r) * T * DEC_D + u;
+    int t = 0;
+    for (; t + 16 <= T; t += 16) {
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = xr[(long)(t + i) * DEC_D];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += energy[r][t + i] * v[i];
+    }
+    for (; t < T; ++t) s += energy[r][t] * xr[(long)t * DEC_D];
+    float* ip = p.inp + (long)(r0 + r) * (2 * DEC_D);
+    ip[u] = p.emb[(long)ycur[r] * DEC_D + u];
+    ip[DEC_D + u] = s;
+  }
+}
+
+// h_next = GRUCell(inp, h_prev): grid (ceil(R/16), D/32).  The workgroup's 96 gate rows (3 gates x 32 units)
+// are 6 row tiles of 16; each tile has three K-slices of 256 (W_ih[:, :256], W_ih[:, 256:], W_hh) = 18 MFMA
+// jobs of 64 MFMAs, dealt round-robin to the 4 wavefronts; slices are summed in the pointwise phase.
+__global__ __launch_bounds__(256) void dec_gru_kernel(DecParams p, const float* __restrict__ hprev, float* __restrict__ hnext) {
+  __shared__ __attribute__((aligned(16))) float xin[GRU_RB][2 * DEC_D + 4];
+  __shared__ __attribute__((aligned(16))) float hs[GRU_RB][DEC_D + 4];
+  __shared__ float gbuf[3][GRU_RB][3 * GRU_UB + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * GRU_RB, ub = blockIdx.y;
+  const int nr = min(GRU_RB, p.R - r0);
+  for (int i = tid; i < GRU_RB * (2 * DEC_D / 4); i += 256) {
+    const int r = i / (2 * DEC_D / 4), k4 = i % (2 * DEC_D / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nr) v = reinterpret_cast<const float4*>(p.inp + (long)(r0 + r) * (2 * DEC_D))[k4];
+    *reinterpret_cast<float4*>(&xin[r][k4 * 4]) = v;
+  }
+  for (int i = tid; i < GRU_RB * (DEC_D / 4); i += 256) {
+    const int r = i / (DEC_D / 4), k4 = i % (DEC_D / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nr) v = reinterpret_cast<const float4*>(hprev + (long)(r0 + r) * DEC_D)[k4];
+    *reinterpret_cast<float4*>(&hs[r][k4 * 4]) = v;
+  }
+  __syncthreads();
+  for (int job = wave; job < 18; job += 4) {
+    const int tile = job / 3, part = job - tile * 3;        // part 0/1: W_ih column halves, 2: W_hh
+    const int g = tile >> 1, uh = tile & 1;
+    const int row0 = g * DEC_D + ub * GRU_UB + uh * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (part < 2) mfma_rows16<DEC_D>(p.w_ih + part * DEC_D, 2 * DEC_D, row0, &xin[0][part * DEC_D], 2 * DEC_D + 4, lane, acc);
+    else mfma_rows16<DEC_D>(p.w_hh, DEC_D, row0, &hs[0][0], DEC_D + 4, lane, acc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gbuf[part][lane & 15][g * GRU_UB + uh * 16 + (lane >> 4) * 4 + e] = acc[e];
+  }
+  __syncthreads();
+  for (int i = tid; i < GRU_RB * GRU_UB; i += 256) {
+    const int r = i / GRU_UB, ul = i % GRU_UB;
+    if (r < nr) {
+      const int u = ub * GRU_UB + ul;
+      const float ir = gbuf[0][r][ul] + gbuf[1][r][ul] + p.b_ih[u];
+      const float iz = gbuf[0][r][GRU_UB + ul] + gbuf[1][r][GRU_UB + ul] + p.b_ih[DEC_D + u];
+      const float in_ = gbuf[0][r][2 * GRU_UB + ul] + gbuf[1][r][2 * GRU_UB + ul] + p.b_ih[2 * DEC_D + u];
+      const float hr = gbuf[2][r][ul] + p.b_hh[u];
+      const float hz = gbuf[2][r][GRU_UB + ul] + p.b_hh[DEC_D + u];
+      const float hn = gbuf[2][r][2 * GRU_UB + ul] + p.b_hh[2 * DEC_D + u];
+      const float rg = sigmoidf_(ir + hr), zg = sigmoidf_(iz + hz);
+      const float ng = tanhf(in_ + rg * hn);
+      hnext[(long)(r0 + r) * DEC_D + u] = (1.f - zg) * ng + zg * hs[r][u];
+    }
   }
 }
 
@@ -422,21 +542,39 @@ __global__ void decode_break_mask_kernel(const int* __restrict__ pred, const int
   }
 }
 
+extern "C" int64_t glass_decode_workspace_bytes(int R, int D) {
+  return (int64_t)((size_t)R * D * 2 + (size_t)R * 2 * D) * sizeof(float) + (int64_t)R * sizeof(int);
+}
+
 extern "C" int glass_attention_decode(const float* x, const float* xproj, const glass_decoder_weights* w, const int* roi_image,
                                       int R, int num_images, int T, int D, int C, int max_len, int eos, float* out,
-                                      int* pred_scratch, glass_stream_t stream) {
+                                      int* pred_scratch, void* workspace, int64_t workspace_bytes, glass_stream_t stream) {
   GLASS_CHECK_ARG(D == DEC_D && T > 0 && T <= DEC_TMAX && C > 0 && C <= DEC_CMAX && max_len > 0,
                   "glass_attention_decode: needs D=256, T<=64, C<=256 (got D=%d T=%d C=%d)", D, T, C);
   if (R == 0) return GLASS_OK;
-  GLASS_CHECK_ARG(x && xproj && w && roi_image && out && pred_scratch && num_images > 0, "glass_attention_decode: null pointer");
+  GLASS_CHECK_ARG(x && xproj && w && roi_image && out && pred_scratch && num_images > 0 && workspace,
+                  "glass_attention_decode: null pointer");
+  GLASS_CHECK_ARG(workspace_bytes >= glass_decode_workspace_bytes(R, D), "glass_attention_decode: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
   DecParams p;
   p.x = x; p.xproj = xproj; p.sW = w->sW; p.sB = w->sB; p.wW = w->wW; p.wB = w->wB; p.emb = w->emb; p.w_ih = w->w_ih;
   p.w_hh = w->w_hh; p.b_ih = w->b_ih; p.b_hh = w->b_hh; p.fcW = w->fcW; p.fcB = w->fcB; p.temperature = w->temperature;
   p.R = R; p.T = T; p.C = C; p.max_len = max_len; p.out = out; p.pred = pred_scratch;
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(cdiv(R, DEC_RB)), dim3(256), 0, (hipStream_t)stream, p);
+  float* ws = static_cast<float*>(workspace);
+  p.h0 = ws; p.h1 = ws + (size_t)R * D; p.inp = ws + (size_t)R * D * 2;
+  p.yprev = reinterpret_cast<int*>(ws + (size_t)R * D * 4);
+  hipError_t e = hipMemsetAsync(p.h0, 0, (size_t)R * D * sizeof(float), s);      // initial state h = 0
+  if (e != hipSuccess) { glass_set_error("glass_attention_decode: memset: %s", hipGetErrorString(e)); return GLASS_EHIP; }
+  const dim3 ga(cdiv(R, DEC_RB)), gg(cdiv(R, GRU_RB), DEC_D / GRU_UB);
+  float* hb[2] = {p.h0, p.h1};
+  hipLaunchKernelGGL(dec_fc_att_kernel, ga, dim3(256), 0, s, p, hb[0], -1, 1);               // attention for step 0
+  for (int step = 0; step < max_len; ++step) {
+    hipLaunchKernelGGL(dec_gru_kernel, gg, dim3(256), 0, s, p, hb[step & 1], hb[(step + 1) & 1]);
+    hipLaunchKernelGGL(dec_fc_att_kernel, ga, dim3(256), 0, s, p, hb[(step + 1) & 1], step, step + 1 < max_len ? 1 : 0);
+  }
   GLASS_CHECK_LAUNCH("glass_attention_decode");
-  hipLaunchKernelGGL(decode_break_mask_kernel, dim3(num_images), dim3(256), 0, (hipStream_t)stream, pred_scratch, roi_image, R,
-                     max_len, C, eos, out);
+  hipLaunchKernelGGL(decode_break_mask_kernel, dim3(num_images), dim3(256), 0, s, pred_scratch, roi_image, R, max_len, C, eos,
+                     out);
   GLASS_CHECK_LAUNCH("glass_attention_decode(mask)");
   return GLASS_OK;
 }

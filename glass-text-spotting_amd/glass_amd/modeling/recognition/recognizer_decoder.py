@@ -45,8 +45,8 @@ class ASTER_V2(InferenceModule):
             "wW": dev(f("attention_unit.wEmbed.weight").reshape(-1), device),
             "wB": dev(f("attention_unit.wEmbed.bias").reshape(-1), device),
             "emb": dev(f("tgt_embedding.weight"), device),
-            "w_ih": dev(K.pack_kblocked(f("gru.weight_ih_l0")), device),
-            "w_hh": dev(K.pack_kblocked(f("gru.weight_hh_l0")), device),
+            "w_ih": dev(f("gru.weight_ih_l0"), device),          # [3D, 2D] row-major (MFMA GRU kernel)
+            "w_hh": dev(f("gru.weight_hh_l0"), device),          # [3D, D]
             "b_ih": dev(f("gru.bias_ih_l0"), device),
             "b_hh": dev(f("gru.bias_hh_l0"), device),
             "fcW": dev(K.pack_kblocked(f("fc.weight")), device),

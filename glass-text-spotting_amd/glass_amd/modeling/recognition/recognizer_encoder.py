@@ -36,8 +36,7 @@ class BiLSTMBlockV2(InferenceModule):
             w_ih = torch.cat([sd[q + "rnn.weight_ih_l0"], sd[q + "rnn.weight_ih_l0_reverse"]], 0)      # [2*4H, I]
             b = torch.cat([sd[q + "rnn.bias_ih_l0"] + sd[q + "rnn.bias_hh_l0"],
                            sd[q + "rnn.bias_ih_l0_reverse"] + sd[q + "rnn.bias_hh_l0_reverse"]], 0)
-            w_hh = torch.stack([K.pack_kblocked(sd[q + "rnn.weight_hh_l0"].float()),
-                                K.pack_kblocked(sd[q + "rnn.weight_hh_l0_reverse"].float())], 0)
+            w_hh = torch.stack([sd[q + "rnn.weight_hh_l0"].float(), sd[q + "rnn.weight_hh_l0_reverse"].float()], 0)
             self.layers.append({"w_ih": dev(w_ih, device), "b": dev(b, device), "w_hh": dev(w_hh, device),
                                 "lin_w": dev(sd[q + "linear.weight"], device), "lin_b": dev(sd[q + "linear.bias"], device)})
 

@@ -280,8 +280,13 @@ def bilstm_recurrence(xg: torch.Tensor, w_hh_packed: torch.Tensor, hidden: int) 
     _f32c(xg, "xg"); _f32c(w_hh_packed, "w_hh_packed")
     R, T = xg.shape[0], xg.shape[1]
     out = torch.empty((R, T, 2 * hidden), dtype=torch.float32, device=xg.device)
+    if R == 0:
+        return out
+    nbytes = int(lib().glass_bilstm_workspace_bytes(R, hidden))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=xg.device)
     check(lib().glass_bilstm_recurrence(c_void_p(_dev(xg)), c_void_p(_dev(w_hh_packed)), c_void_p(_dev(out)), R, T, hidden,
-                                        c_void_p(stream_handle())), "glass_bilstm_recurrence")
+                                        c_void_p(_dev(ws)), ctypes.c_int64(nbytes), c_void_p(stream_handle())),
+          "glass_bilstm_recurrence")
     return out
 
 
@@ -298,9 +303,12 @@ def attention_decode(x: torch.Tensor, xproj: torch.Tensor, weights: dict, roi_im
     for n in ("sW", "sB", "wW", "wB", "emb", "w_ih", "w_hh", "b_ih", "b_hh", "fcW", "fcB"):
         setattr(w, n, _dev(_f32c(weights[n], n)))
     w.temperature = float(weights["temperature"])
+    nbytes = int(lib().glass_decode_workspace_bytes(R, D))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     check(lib().glass_attention_decode(c_void_p(_dev(x)), c_void_p(_dev(xproj)), ctypes.byref(w), c_void_p(_dev(roi_image)),
                                        R, int(num_images), T, D, int(num_classes), int(max_len), int(eos),
-                                       c_void_p(_dev(out)), c_void_p(_dev(pred)), c_void_p(stream_handle())),
+                                       c_void_p(_dev(out)), c_void_p(_dev(pred)), c_void_p(_dev(ws)), ctypes.c_int64(nbytes),
+                                       c_void_p(stream_handle())),
           "glass_attention_decode")
     return out
 

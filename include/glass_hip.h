@@ -187,10 +187,12 @@ int glass_mean_over_h(const float* x, float* y, int R, int H, int W, int C, glas
  * state; glass/modeling/recognition/recognizer_encoder.py:123-144).  The input projection
  * xg = x @ W_ih^T + b_ih + b_hh for both directions is computed beforehand with
  * glass_conv2d_nhwc: xg [R,T,2,4*Hd] (direction-major, then gate-major i,f,g,o).
- * w_hh_packed [2][Hd/4][4*Hd][4] (k-blocked, per direction).  out [R,T,2*Hd] (fwd | bwd).
- * Requires Hd == 256.                                                                     */
-int glass_bilstm_recurrence(const float* xg, const float* w_hh_packed, float* out, int R, int T, int Hd,
-                            glass_stream_t stream);
+ * w_hh [2][4*Hd][Hd] (nn.LSTM layout, forward then reverse direction).  out [R,T,2*Hd] (fwd | bwd).
+ * `workspace`: device scratch (hidden/cell state) of >= glass_bilstm_workspace_bytes().  Requires Hd == 256.
+ * Implementation note: T step launches are issued by this one call (each step is spread over the chip).                                                                    */
+int64_t glass_bilstm_workspace_bytes(int R, int Hd);
+int glass_bilstm_recurrence(const float* xg, const float* w_hh, float* out, int R, int T, int Hd, void* workspace,
+                            int64_t workspace_bytes, glass_stream_t stream);
 
 /* ------------------------------------------------------------------ attention decoder
  * Greedy additive-attention GRU decoder (AttentionRecognitionHead.sample,
@@ -199,17 +201,20 @@ int glass_bilstm_recurrence(const float* xg, const float* w_hh_packed, float* ou
  * steps after every RoI OF THE SAME IMAGE has emitted `eos` stay zero) is applied as a
  * mask using roi_image [R] (image id per RoI in [0,num_images), non-decreasing).
  * x [R,T,D]; xproj [R,T,D] = xEmbed(x) precomputed with glass_conv2d_nhwc (it is
- * step-invariant).  Weights (k-blocked packing above): sW [D/4][D][4], sB [D], wW [D],
- * wB [1], emb [C][D] (row-major), w_ih [2D/4][3D][4] (input = [embedding | context]),
- * w_hh [D/4][3D][4], b_ih [3D], b_hh [3D], fcW [D/4][C][4], fcB [C], temperature (host).
- * out [R,max_len,C] softmax probabilities.  Requires D == 256, T <= 64, C <= 256.         */
+ * step-invariant).  Weights: sW [D/4][D][4] and fcW [D/4][C][4] in the k-blocked packing above; sB [D],
+ * wW [D], wB [1], emb [C][D], w_ih [3D][2D] and w_hh [3D][D] row-major (nn.GRU layout; input =
+ * [embedding | context]), b_ih [3D], b_hh [3D], fcB [C], temperature (host).
+ * out [R,max_len,C] softmax probabilities; pred_scratch [R,max_len] ints; `workspace`: device scratch of
+ * >= glass_decode_workspace_bytes().  Requires D == 256, T <= 64, C <= 256.  Two step launches per
+ * decoding step are issued by this one call.                                                */
 typedef struct glass_decoder_weights {
   const float *sW, *sB, *wW, *wB, *emb, *w_ih, *w_hh, *b_ih, *b_hh, *fcW, *fcB;
   float temperature;
 } glass_decoder_weights;
+int64_t glass_decode_workspace_bytes(int R, int D);
 int glass_attention_decode(const float* x, const float* xproj, const glass_decoder_weights* w, const int* roi_image, int R,
                            int num_images, int T, int D, int C, int max_len, int eos, float* out, int* pred_scratch,
-                           glass_stream_t stream);
+                           void* workspace, int64_t workspace_bytes, glass_stream_t stream);
 
 #ifdef __cplusplus
 }
