@@ -6,8 +6,9 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path (`GlassRCNN.inference`: preprocess -> ResNet-50+FPN ->
-rotated RPN -> box head -> rotated RoIAlign -> local extractor -> fusion attention -> recognizer)
-over one batch of 8 synthetic 1000x1000 images per GPU with 32 word RoIs per image
+rotated RPN -> box head -> rotated RoIAlign -> local extractor -> fusion attention -> recognizer
+-> meta-arch postprocess) followed by the word post-processor (PostProcessorAcademic: merge,
+thresholds, polygons, text decode) over one batch of 8 synthetic 1000x1000 images per GPU with 32 word RoIs per image
 (BASELINE.json configs[2] = the configuration the metric "images/sec/GPU end-to-end spotting,
 1000x1000, ~32 RoIs" is quoted on).  Inputs (float CHW images, injected word boxes) are resident
 in HBM before the timed region.  Because random-init weights do not yield ~32 sensible word
@@ -126,7 +127,8 @@ def main():
 
     import glass_amd
     from glass_amd.config import get_glass_cfg
-    from glass_amd.distributed import all_gather_records, pack_padded
+    from glass_amd.distributed import all_gather_records, pack_words
+    from glass_amd.postprocess import build_post_processor
     from glass_amd.ops import native as K
     from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
 
@@ -141,6 +143,8 @@ def main():
     boxes = [make_boxes(g, args.rois, args.side, args.side).to(dev) for g in gidx]
     inputs = [{"image": im} for im in images]
     max_det = cfg.TEST.DETECTIONS_PER_IMAGE
+    post = build_post_processor(cfg)                              # PostProcessorAcademic (device kernel)
+    out_sizes = [(args.side, args.side)] * B
     steps_txt = cfg.MODEL.ROI_RECOGNIZER_HEAD.MAX_WORD_LENGTH + 1
 
     if args.workload == "backbone":
@@ -150,8 +154,11 @@ def main():
         if args.workload == "backbone":                           # BASELINE configs[1]: trunk + FPN only
             model.backbone.forward_nhwc(il.nhwc4)
             return torch.zeros((B, 1), device=dev)
-        model.inference(inputs, override_boxes=boxes)            # list[{"instances": Instances}] (views) ...
-        return pack_padded(model.last_batch, max_det, steps_txt)  # ... + the padded batch for the gather
+        model.inference(inputs, override_boxes=boxes)            # list[{"instances": Instances}] (views)
+        det = model.last_batch                                    # + the padded device-resident batch
+        # word post-processing (merge, thresholds, polygons, text decode + text-score filter) for the 8 images
+        post.process_padded(det.boxes, det.scores, det.counts_dev, det.text, None, out_sizes, {"orientations": det.orient})
+        return pack_words(post.last_words, max_det, steps_txt)    # fixed-size per-image word records
 
     def step():
         rec = local_step()

@@ -88,6 +88,48 @@ def pack_padded(det, max_det: int, steps: int) -> torch.Tensor:
     return rec
 
 
+def words_record_size(max_det: int, steps: int) -> int:
+    return 1 + max_det * (5 + 1 + 1 + 8 + 1 + steps)
+
+
+def pack_words(words: dict, max_det: int, steps: int) -> torch.Tensor:
+    """Record of the POST-PROCESSED words of a step (the padded outputs of ops.native.postprocess_words):
+    [count | boxes 5D | score D | text score D | polygon 8D | text length D | character index D*T]."""
+    N, K = words["scores"].shape
+    dev = words["scores"].device
+    D = max_det
+    k = min(K, D)
+    T = min(steps, words["char"].shape[2])
+    rec = torch.zeros((N, words_record_size(D, steps)), dtype=torch.float32, device=dev)
+    rec[:, 0] = words["count"].clamp(max=D).float()
+    o = 1
+    rec[:, o:o + 5 * D].view(N, D, 5)[:, :k] = words["boxes"][:, :k]; o += 5 * D
+    rec[:, o:o + D][:, :k] = words["scores"][:, :k]; o += D
+    rec[:, o:o + D][:, :k] = words["text_score"][:, :k]; o += D
+    rec[:, o:o + 8 * D].view(N, D, 8)[:, :k] = words["polygons"][:, :k].reshape(N, k, 8); o += 8 * D
+    rec[:, o:o + D][:, :k] = words["text_len"][:, :k].float(); o += D
+    rec[:, o:o + D * steps].view(N, D, steps)[:, :k, :T] = words["char"][:, :k, :T].float()
+    return rec
+
+
+def unpack_words(rec: torch.Tensor, max_det: int, steps: int, characters: Sequence[str]) -> List[dict]:
+    """-> per image {boxes, scores, text_scores, polygons, texts}"""
+    out = []
+    D = max_det
+    for i in range(rec.shape[0]):
+        k = int(rec[i, 0].item())
+        o = 1
+        boxes = rec[i, o:o + 5 * D].view(D, 5)[:k]; o += 5 * D
+        scores = rec[i, o:o + D][:k]; o += D
+        tscores = rec[i, o:o + D][:k]; o += D
+        polys = rec[i, o:o + 8 * D].view(D, 4, 2)[:k]; o += 8 * D
+        lens = rec[i, o:o + D][:k].long().tolist(); o += D
+        chars = rec[i, o:o + D * steps].view(D, steps)[:k].long().tolist()
+        texts = ["".join(characters[c] for c in chars[j][:lens[j]]) for j in range(k)]
+        out.append({"boxes": boxes, "scores": scores, "text_scores": tscores, "polygons": polys, "texts": texts})
+    return out
+
+
 def unpack_results(rec: torch.Tensor, image_sizes: Sequence[Tuple[int, int]], max_det: int, steps: int,
                    classes: int = 0) -> List[Instances]:
     out = []

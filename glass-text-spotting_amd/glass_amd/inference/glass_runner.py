@@ -82,20 +82,33 @@ class GlassRunner:
         for i, inp in enumerate(inputs):
             key = ((inp["height"] + d - 1) // d * d, (inp["width"] + d - 1) // d * d)
             groups.setdefault(key, []).append(i)
-        raw = [None] * len(inputs)
+        out = [None] * len(inputs)
         for idxs in groups.values():
-            for i, res in zip(idxs, self.model([inputs[i] for i in idxs])):
-                raw[i] = res
-        out = []
-        for res, r, (h, w) in zip(raw, ratios, shapes):
-            preds = res["instances"]
-            if r != 1:
-                preds.pred_boxes.scale(1 / r, 1 / r)
-            preds._image_size = (h, w)
-            self.logger.info(f"Detected {len(preds)} raw word instances")
-            if self.post_process_flag:
-                preds = self.post_processor(preds)
-            out.append(preds)
+            raw = self.model([inputs[i] for i in idxs])
+            if self.post_process_flag and self.model.last_batch is not None:
+                # un-scale + the whole word post-processing for the group in one kernel (no per-image host loop)
+                det = self.model.last_batch
+                if det.text is None and sum(det.counts_host) > 0:
+                    raise RuntimeError("recognizer output missing")
+                sc = torch.tensor([[1.0 / ratios[i], 1.0 / ratios[i]] for i in idxs], dtype=torch.float32).to(self.device)
+                text = det.text
+                if text is None:          # no detections in the whole group
+                    T = self.cfg.MODEL.ROI_RECOGNIZER_HEAD.MAX_WORD_LENGTH + 1
+                    C = len(self.cfg.MODEL.ROI_RECOGNIZER_HEAD.CHARACTER_SET) + 2
+                    text = torch.zeros(tuple(det.scores.shape) + (T, C), dtype=torch.float32, device=self.device)
+                res = self.post_processor.process_padded(det.boxes, det.scores, det.counts_dev, text, sc,
+                                                         [shapes[i] for i in idxs], {"orientations": det.orient})
+                for i, r in zip(idxs, res):
+                    out[i] = r
+            else:
+                for i, res in zip(idxs, raw):
+                    preds = res["instances"]
+                    if ratios[i] != 1:
+                        preds.pred_boxes.scale(1 / ratios[i], 1 / ratios[i])
+                    preds._image_size = tuple(shapes[i])
+                    out[i] = preds
+        for r in out:
+            self.logger.info(f"Post-processing output is {len(r)} word instances")
         return out
 
     def __call__(self, original_image: np.ndarray) -> Instances:

@@ -333,3 +333,32 @@ def detections_finalize(boxes: torch.Tensor, scores: torch.Tensor, orient: Optio
         c_void_p(_dev(ob)), c_void_p(_dev(os_)), opt(oo), opt(ot), c_void_p(_dev(oc)), c_void_p(stream_handle())),
         "glass_detections_finalize")
     return ob, os_, oo, ot, oc
+
+
+def postprocess_words(boxes: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor, text: Optional[torch.Tensor],
+                      scale_xy: Optional[torch.Tensor], thresholds8: Sequence[float], stop_index: int) -> dict:
+    """boxes [N,K,5], scores [N,K], counts int32 [N], text [N,K,T,C]|None -> dict of padded outputs."""
+    _f32c(boxes, "boxes"); _f32c(scores, "scores"); _i32(counts, "counts")
+    N, K, _ = boxes.shape
+    dev = boxes.device
+    T, C = (int(text.shape[2]), int(text.shape[3])) if text is not None else (1, 1)
+    out = {"boxes": torch.zeros((N, K, 5), dtype=torch.float32, device=dev),
+           "scores": torch.zeros((N, K), dtype=torch.float32, device=dev),
+           "polygons": torch.zeros((N, K, 4, 2), dtype=torch.float32, device=dev),
+           "src": torch.zeros((N, K), dtype=torch.int32, device=dev),
+           "char": torch.zeros((N, K, T), dtype=torch.int32, device=dev),
+           "text_score": torch.zeros((N, K), dtype=torch.float32, device=dev),
+           "text_len": torch.zeros((N, K), dtype=torch.int32, device=dev),
+           "count": torch.zeros((N,), dtype=torch.int32, device=dev)}
+    thr = (c_float * 8)(*[float(v) for v in thresholds8])
+    opt = lambda t: c_void_p(_dev(t)) if t is not None else c_void_p(None)
+    if text is not None:
+        _f32c(text, "text")
+    if scale_xy is not None:
+        _f32c(scale_xy, "scale_xy")
+    check(lib().glass_postprocess_words(
+        c_void_p(_dev(boxes)), c_void_p(_dev(scores)), c_void_p(_dev(counts)), opt(text), opt(scale_xy), N, K, T, C, thr,
+        int(stop_index), c_void_p(_dev(out["boxes"])), c_void_p(_dev(out["scores"])), c_void_p(_dev(out["polygons"])),
+        c_void_p(_dev(out["src"])), c_void_p(_dev(out["char"])), c_void_p(_dev(out["text_score"])),
+        c_void_p(_dev(out["text_len"])), c_void_p(_dev(out["count"])), c_void_p(stream_handle())), "glass_postprocess_words")
+    return out

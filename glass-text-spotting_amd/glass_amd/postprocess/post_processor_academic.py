@@ -17,6 +17,15 @@ from .post_processor_rotated_boxes import POST_PROCESSOR_REGISTRY, PostProcessor
 _SPECIAL = str("'!?.:,*+\"()·[]/\\#$%;<=>@^_`{|}~")
 
 
+def strip_special(text: str) -> str:
+    """strip ONE leading and ONE trailing special character (text_evaluator.py:337-343)"""
+    if len(text) > 0 and _SPECIAL.find(text[0]) > -1:
+        text = text[1:]
+    if len(text) > 0 and _SPECIAL.find(text[-1]) > -1:
+        text = text[:-1]
+    return text
+
+
 def get_instances_text(text_probs, text_encoder, onlyRemoveFirstLastCharacter=True):
     if len(text_probs):
         text_probs = text_probs.detach().cpu()
@@ -43,8 +52,8 @@ class PostProcessorAcademic(PostProcessorRotatedBoxes):
         self.text_threshold = cfg.POST_PROCESSING.TEXT_THRESHOLD
         self.text_encoder = TextEncoder(cfg)
 
-    def __call__(self, preds, scale_ratio=1, **kwargs):
-        preds = super().__call__(preds)
+    def host_call(self, preds, scale_ratio=1, **kwargs):
+        preds = super().host_call(preds)
         texts, text_scores, _ = get_instances_text(preds.pred_text_prob, self.text_encoder)
         keep = torch.tensor(text_scores) >= self.text_threshold
         return preds[keep.to(preds.pred_boxes.device) if len(text_scores) else torch.zeros((0,), dtype=torch.bool)]

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from ..structures.boxes import nms_rotated, pairwise_ioa_rotated
-from ..structures.core import Instances
+from ..structures.core import Instances, RotatedBoxes
 from ..utils.registry import Registry
 
 POST_PROCESSOR_REGISTRY = Registry("POST_PROCESSOR")
@@ -101,7 +101,79 @@ class PostProcessorRotatedBoxes:
             "Valid score threshold must be smaller than the other class thresholds, to prevent word-in-word  cases"
         self.max_angle_diff = pp.MAX_ANGLE_DIFF
 
-    def __call__(self, preds: Instances):
+    # ------------------------------------------------------------------ device path (default)
+    text_threshold = None          # set by PostProcessorAcademic
+    text_encoder = None
+
+    def _thresholds(self):
+        return [float(self.min_box_dim), float(self.valid_score), float(self.detect_threshold),
+                float(self.merge_ioa_thresh), float(self.pairs_height_ratio_thresh), float(self.max_angle_diff),
+                float(self.minimal_ioa_thresh), float(self.text_threshold if self.text_threshold is not None else 0.0)]
+
+    def process_padded(self, boxes, scores, counts_dev, text, scale_xy, image_sizes, extra=None):
+        """All images of a step in ONE kernel (ops.native.postprocess_words) + one read of the compact
+        results.  boxes [N,K,5], scores [N,K], text [N,K,T,C]|None (None: no text filter), scale_xy [N,2]|None.
+        `extra`: dict name -> padded [N,K,...] tensors gathered along with the survivors."""
+        from ..ops import native as K
+        use_text = text is not None and self.text_threshold is not None
+        stop = self.text_encoder.character.index("[s]") if use_text else 1
+        out = K.postprocess_words(boxes, scores, counts_dev, text if use_text else None, scale_xy, self._thresholds(), stop)
+        self.last_words = out              # padded device tensors of this call (distributed.pack_words)
+        counts = out["count"].cpu().tolist()
+        chars = out["char"].cpu().numpy() if use_text else None
+        tlen = out["text_len"].cpu().tolist() if use_text else None
+        results = []
+        for n, size in enumerate(image_sizes):
+            c = counts[n]
+            r = Instances(tuple(size))
+            r.pred_boxes = RotatedBoxes(out["boxes"][n, :c])
+            r.scores = out["scores"][n, :c]
+            r.pred_classes = torch.zeros((c,), dtype=torch.int64, device=boxes.device)
+            src = out["src"][n, :c].long()
+            if text is not None:
+                r.pred_text_prob = text[n][src]
+            for name, t in (extra or {}).items():
+                if t is not None:
+                    r.set(name, t[n][src])
+            r.pred_polygons = out["polygons"][n, :c]
+            if use_text:
+                from .post_processor_academic import strip_special
+                r.pred_text_scores = out["text_score"][n, :c]
+                r.pred_texts = [strip_special("".join(self.text_encoder.character[int(i)] for i in chars[n, j, :tlen[n][j]]))
+                                for j in range(c)]
+            results.append(r)
+        return results
+
+    def __call__(self, preds: Instances, **kwargs):
+        """Reference call convention (one image's Instances in, Instances out) on the device kernel."""
+        if self.skip_all:
+            self.logger.warning('SKIPPING POST PROCESSING - "SKIP_ALL" is "True" in config file')
+            return preds
+        n = len(preds)
+        dev = preds.pred_boxes.tensor.device
+        if n == 0 and not preds.has("pred_text_prob") and self.text_threshold is not None:
+            _ = preds.pred_text_prob          # reference behaviour: AttributeError on a detection-less image
+        K_ = max(n, 1)
+        boxes = torch.zeros((1, K_, 5), dtype=torch.float32, device=dev)
+        scores = torch.zeros((1, K_), dtype=torch.float32, device=dev)
+        boxes[0, :n] = preds.pred_boxes.tensor
+        scores[0, :n] = preds.scores
+        text = None
+        if preds.has("pred_text_prob"):
+            tp = preds.pred_text_prob
+            text = torch.zeros((1, K_) + tuple(tp.shape[1:]), dtype=torch.float32, device=dev)
+            text[0, :n] = tp
+        extra = {}
+        if preds.has("orientations"):
+            o = torch.zeros((1, K_, 2), dtype=torch.float32, device=dev)
+            o[0, :n] = preds.orientations
+            extra["orientations"] = o
+        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        return self.process_padded(boxes, scores, cnt, text, None, [preds.image_size], extra)[0]
+
+    # ------------------------------------------------------------------ host restatement (kept as the readable
+    # statement of the semantics and as a cross-check of the kernel in tests; ~56 ms per image)
+    def host_call(self, preds: Instances):
         if self.skip_all:
             self.logger.warning('SKIPPING POST PROCESSING - "SKIP_ALL" is "True" in config file')
             return preds

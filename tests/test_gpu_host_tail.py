@@ -94,6 +94,7 @@ def test_academic_postprocessor_runs_end_to_end():
     assert out.pred_polygons.shape == (n, 4, 2) and out.pred_text_prob.shape[0] == n
     texts, scores, _ = get_instances_text(out.pred_text_prob, runner.text_encoder)
     assert len(texts) == n and all(0.0 <= s <= 1.0 for s in scores)
+    assert out.pred_texts == texts
 
 
 def test_batched_postprocess_kernel_equals_listwise_reference_logic_and_pack():
@@ -142,3 +143,71 @@ def test_batched_postprocess_kernel_equals_listwise_reference_logic_and_pack():
     rec_a = pack_results([x["instances"] for x in batched], 100, 26)
     rec_b = pack_padded(m.last_batch, 100, 26)
     assert torch.equal(rec_a, rec_b)
+
+
+def test_device_postprocessor_equals_host_restatement_with_text():
+    """PostProcessorAcademic: the one-kernel device path vs the readable host restatement (host_call) on random
+    detections with overlapping boxes and random text distributions (merge order, NMS re-ordering, text filter)."""
+    from glass_amd.postprocess import build_post_processor
+    from glass_amd.structures.core import Instances, RotatedBoxes
+    from glass_amd.utils.synth import make_boxes
+    dev = torch.device("cuda:0")
+    pp = build_post_processor(_cfg(["POST_PROCESSING.TEXT_THRESHOLD", 0.01]))
+    g = torch.Generator().manual_seed(11)
+    for case in range(7):
+        n = [40, 1, 17, 64, 100, 8, 7][case]
+        # (dense random scenes cascade into chaotic merge chains where a 1-ulp difference flips a threshold
+        #  test; keep the scenes moderately dense so host and device must agree step for step)
+        b = make_boxes(50 + case, n, 1000, 1400)
+        if n > 4:                                     # force overlapping near-duplicates -> merges
+            b[1] = b[0] + torch.tensor([8.0, 1.0, 2.0, 0.5, 1.0])
+            b[3] = b[2] + torch.tensor([-6.0, 0.5, -3.0, 0.2, -2.0])
+        if case == 6:                                 # a 6-box chain along a 20-degree line + one crossing box:
+            ang = np.deg2rad(20.0)                    # merges cascade over several iterations
+            b = torch.tensor([[300 + 50 * i * np.cos(ang), 300 - 50 * i * np.sin(ang), 90.0, 24.0 + i, 20.0 + 0.5 * i]
+                              for i in range(6)] + [[400.0, 260.0, 90.0, 24.0, -70.0]], dtype=torch.float32)
+        n = len(b)
+        s = torch.rand((n,), generator=g) * 0.9 + 0.1
+        logits = torch.randn((n, 26, 97), generator=g) * 6
+        logits[:, 3 + case % 5, 1] += 30.0            # a stop symbol somewhere
+        tp = torch.softmax(logits, -1)
+
+        def mk():
+            inst = Instances((300, 400))
+            inst.pred_boxes = RotatedBoxes(b.clone().to(dev))
+            inst.scores = s.clone().to(dev)
+            inst.pred_classes = torch.zeros(n, dtype=torch.int64, device=dev)
+            inst.orientations = torch.stack([torch.arange(n).float(), s], 1).to(dev)
+            inst.pred_text_prob = tp.clone().to(dev)
+            return inst
+        host = pp.host_call(mk())
+        devr = pp(mk())
+        assert len(host) == len(devr), (case, len(host), len(devr))
+        # chains of merges amplify the 1-ulp sin/cos differences between torch-CPU and the device (fp32 polygons ->
+        # float64 min-area-rect): relative 2e-3 on boxes that went through several merges
+        np.testing.assert_allclose(devr.pred_boxes.tensor.cpu().numpy(), host.pred_boxes.tensor.cpu().numpy(), rtol=2e-3, atol=0.05)
+        np.testing.assert_allclose(devr.scores.cpu().numpy(), host.scores.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(devr.pred_polygons.cpu().numpy(), host.pred_polygons.cpu().numpy(), rtol=2e-3, atol=0.5)
+        assert torch.equal(devr.orientations.cpu(), host.orientations.cpu())
+        assert torch.equal(devr.pred_text_prob.cpu(), host.pred_text_prob.cpu())
+        from glass_amd.postprocess.post_processor_academic import get_instances_text
+        texts, tscores, _ = get_instances_text(host.pred_text_prob, pp.text_encoder)
+        assert devr.pred_texts == texts
+        np.testing.assert_allclose(devr.pred_text_scores.cpu().numpy(), np.array(tscores, dtype=np.float32), rtol=1e-5, atol=1e-7)
+
+
+def test_runner_batch_with_device_postprocess_equals_single_calls():
+    from glass_amd.inference.glass_runner import GlassRunner
+    from glass_amd.utils.synth import make_image, make_state_dict
+    cfg = _cfg(["INPUT.MIN_SIZE_TEST", 160, "INPUT.MAX_SIZE_TEST", 200, "MODEL.DEVICE", "cuda:0",
+                "POST_PROCESSING.TEXT_THRESHOLD", 0.0, "POST_PROCESSING.DETECT_THRESHOLD", 0.15])
+    runner = GlassRunner(None, None, cfg=cfg, state_dict=make_state_dict(1234), post_process=True)
+    imgs = [make_image(5, 100, 80).numpy(), make_image(6, 150, 250).numpy(), make_image(8, 98, 76).numpy()]
+    single = [runner(im) for im in imgs]
+    batch = runner.run_batch(imgs)
+    for a, b, im in zip(single, batch, imgs):
+        assert a.image_size == tuple(im.shape[:2]) == b.image_size
+        assert len(a) == len(b)
+        np.testing.assert_allclose(a.pred_boxes.tensor.cpu().numpy(), b.pred_boxes.tensor.cpu().numpy(), atol=1e-4)
+        assert a.pred_texts == b.pred_texts
+        assert a.pred_polygons.shape == (len(a), 4, 2)

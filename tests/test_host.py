@@ -190,3 +190,21 @@ def test_product_path_has_no_cpu_fallback():
     out = subprocess.run(["grep", "-rlE", r"^\s*(from|import) oracle", os.path.join(ROOT, "glass-text-spotting_amd")],
                          capture_output=True, text=True).stdout.strip()
     assert out == "", f"product imports the oracle: {out}"
+
+
+def test_word_records_roundtrip():
+    from glass_amd.distributed import pack_words, unpack_words, words_record_size
+    g = torch.Generator().manual_seed(1)
+    N, K, T = 3, 6, 26
+    words = {"boxes": torch.rand((N, K, 5), generator=g), "scores": torch.rand((N, K), generator=g),
+             "text_score": torch.rand((N, K), generator=g), "polygons": torch.rand((N, K, 4, 2), generator=g),
+             "text_len": torch.tensor([[3, 0, 25, 1, 2, 2]] * N, dtype=torch.int32),
+             "char": torch.randint(2, 97, (N, K, T), generator=g, dtype=torch.int32),
+             "count": torch.tensor([2, 0, 6], dtype=torch.int32)}
+    rec = pack_words(words, 100, T)
+    assert rec.shape == (N, words_record_size(100, T))
+    chars = ["[GO]", "[s]"] + [chr(33 + i) for i in range(95)]
+    back = unpack_words(rec, 100, T, chars)
+    assert [len(b["texts"]) for b in back] == [2, 0, 6]
+    assert torch.equal(back[2]["boxes"], words["boxes"][2]) and torch.equal(back[0]["polygons"], words["polygons"][0, :2])
+    assert back[2]["texts"][2] == "".join(chars[int(c)] for c in words["char"][2, 2, :25]) and back[2]["texts"][1] == ""
