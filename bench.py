@@ -191,11 +191,16 @@ def main():
     if rank == 0:
         # dominant kernel (conv_igemm_f32): one extra instrumented step, outside the timed region
         # (rank-local: must not enter a collective the other ranks are not in)
+        # (serial execution: the product overlaps the two halves of the local extractor on two streams,
+        #  which would inflate per-kernel event times)
+        two = model.roi_heads.two_stream_local
+        model.roi_heads.two_stream_local = False
         with ConvMeter(K) as meter:
             local_step()
             conv_ms = meter.total_ms()
             n_launch = len(meter.events)
             conv_flops = meter.flops
+        model.roi_heads.two_stream_local = two
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
         # HBM bytes per launch of the dominant instantiation from the PMC passes kept under profiles/
         # (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 x2 read correction applied)

@@ -15,6 +15,7 @@ Two surfaces:
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -114,6 +115,8 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         if self.mask_inference:
             raise NotImplementedError("rotated mask branch at inference is not built (SURVEY.md §8 f2)")
         self.local_ch = cfg.MODEL.LOCAL_FEATURE_EXTRACTOR.NUM_FEATURES
+        self.two_stream_local = os.environ.get("GLASS_SINGLE_STREAM", "0") != "1"
+        self._streams = None
 
     def import_weights(self, sd, device, prefix: str = "roi_heads.") -> None:
         self.box_head.import_weights(sd, device, prefix + "box_head.")
@@ -150,7 +153,7 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
                             out=xcat, out_coff=1, out_cstride=2)
         crops = K.roi_align_rotated([img_nhwc4], [1.0], boxes, roi_image, self.img_pooler_size, self.img_sampling_ratio,
                                     channels=4)
-        self.hybrid_net.forward_nhwc(crops, out=xcat, out_coff=0, out_cstride=2)
+        self._local_extractor_streams(crops, xcat)
         inter = {"xcat": xcat.clone(), "crops": crops} if return_intermediates else None
         fused = self.fusion_net.forward_interleaved(xcat)
         probs = self.recognizer_head.forward_nhwc(fused, roi_image, num_images)
@@ -158,6 +161,31 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
             inter["fused"] = fused
             return probs, inter
         return probs
+
+    def _local_extractor_streams(self, crops: torch.Tensor, xcat: torch.Tensor) -> None:
+        """Local extractor on all RoIs.  RoIs are independent, so the batch is split in two halves enqueued on
+        two HIP streams: every layer's grid (e.g. 2112 tiles on 768 resident slots at 16x33) ends in a partial
+        wave of tiles, and with two independent streams the idle CUs of one half's tail run the other half's
+        next layer instead of waiting (measured +3.5 % on the whole step: 115.0 vs 111.1 images/s, 3 runs each)."""
+        R = crops.shape[0]
+        if R < 64 or not self.two_stream_local:
+            self.hybrid_net.forward_nhwc(crops, out=xcat, out_coff=0, out_cstride=2)
+            return
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(device=crops.device), torch.cuda.Stream(device=crops.device))
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        h = (R // 2 + 7) // 8 * 8                       # keep both halves' pixel counts tile-friendly
+        parts = ((0, h), (h, R))
+        for st, (a, b) in zip(self._streams, parts):
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                self.hybrid_net.forward_nhwc(crops[a:b], out=xcat[a:b], out_coff=0, out_cstride=2)
+                crops.record_stream(st)
+                xcat.record_stream(st)
+        for st in self._streams:
+            cur.wait_stream(st)
 
     def forward_batched(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor,
                         prop_counts: torch.Tensor, image_sizes: List[Tuple[int, int]],
