@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                     # glass-text-spotting_amd/
 CSRC = os.path.join(_ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_ROOT), "include")
-SO_PATH = os.path.join(_ROOT, "libglass_hip.so")
+SO_PATH = os.environ.get("GLASS_HIP_LIB") or os.path.join(_ROOT, "libglass_hip.so")   # override: kernel experiments
 
 EXPORTS = [
     "glass_last_error", "glass_abi_version", "glass_device_count", "glass_conv2d_nhwc", "glass_maxpool2d_nhwc",
