@@ -1,0 +1,332 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores of gfx950 (3x3, stride 1, pad 1, NHWC fp32).
+//
+// fp32 has no reduced-precision MFMA shortcut on CDNA4 (no TF32), so past ~85% of the 157 TFLOP/s matrix
+// peak the only way to make the 3x3 layers (78% of the path's conv time) faster is to do fewer multiplies:
+// F(2x2,3x3) needs 16 instead of 36 MACs per 2x2 output tile and channel pair (2.25x).
+//
+//   Y(2x2) = At [ sum_c  (G g G^t)  .  (Bt d B) ] A         per output tile, over input channels c
+//
+// which is 16 independent GEMMs  M_xi[tile][cout] = sum_c V_xi[tile][c] * U_xi[c][cout],  xi = 0..15.
+//
+// Work decomposition (one workgroup = 256 threads = 4 waves, ONE workgroup per CU):
+//   * block tile = 64 output tiles (linear over n, tile-row, tile-col) x 64 output channels x all 16 xi;
+//     wave w owns the four xi = 4w..4w+3 (row w of the 4x4 transform domain): 4 xi x (2x2 MFMA blocks of
+//     32x32) = 256 accumulator registers per lane (the whole AGPR half of the unified 512-entry file).
+//   * per k-tile of 16 input channels: thread (tile, 4-channel chunk) fetches the raw 4x4 input patch with
+//     16 bounds-checked buffer_load_dwordx4 (the image border / padding is the hardware's out-of-range
+//     zero fill; the 16 offsets are loop invariant, only the scalar offset advances), applies Bt d B in
+//     registers (128 VALU ops) and writes the 16 transformed float4 to LDS  V[xi][tile][16+4].
+//   * the weight operand never touches LDS: U is pre-packed (glass_winograd_pack_weights) in exact MFMA
+//     B-fragment order, so each wave streams its own xi's fragments L2 -> registers with fully coalesced
+//     1 KiB loads, double buffered one 8-channel group ahead.  No two waves of a block read the same bytes.
+//   * 128 MFMAs (8192 cycles) per wave per k-tile against ~150 VALU + 16 LDS writes + 16 LDS reads + 32
+//     global loads; the next k-tile's patch loads are in flight during the MFMAs.
+//   * epilogue: each wave folds its row of xi with the column half of At . A in registers, the four rows
+//     meet in LDS, and threads (tile, 4-channel chunk) finish At . , add bias / residual, ReLU and store
+//     float4 rows (same epilogue semantics as glass_conv2d_nhwc).
+#include "common.h"
+#include <cstdint>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WT = 64;                        // output tiles (2x2 pixels each) per block
+constexpr int WN = 64;                        // output channels per block
+constexpr int WK = 16;                        // input channels per k-tile
+constexpr int VLD = WK + 4;                   // padded V row (conflict-free ds_read_b128, see conv.hip)
+constexpr int ZLD = WN + 4;
+constexpr int V_FLOATS = 16 * WT * VLD;       // 80 KiB
+constexpr int Z_FLOATS = 4 * 2 * WT * ZLD;    // 136 KiB
+constexpr int WINO_LDS_BYTES = (V_FLOATS > Z_FLOATS ? V_FLOATS : Z_FLOATS) * 4;
+constexpr unsigned OOB = 0x7fffffffu;
+
+struct WinoParams {
+  const float* x;
+  const float* u;
+  const float* bias;
+  const float* res;
+  float* y;
+  int N, H, W, Cin, Cout, TH, TW, ntiles, nk;
+  int ldx, ldy, ycoff, ldr, relu, res_mode;
+  int tiles_m, tiles_n;
+  unsigned x_bytes, u_bytes;
+};
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float comp(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  // XCD-aware tile map (see conv.hip): contiguous run of logical tiles per XCD, cout-blocks innermost so the
+  // blocks that share an input patch run side by side on one L2
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nblk >> 3, r8 = nblk & 7;
+  const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+  const int tile_m = logical / p.tiles_n;
+  const int tile_n = logical - tile_m * p.tiles_n;
+  const int t0 = tile_m * WT, n0 = tile_n * WN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tpi = p.TH * p.TW;
+
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
+
+  // ---- input role: thread = (tile tl, 4-channel chunk) ----
+  const int chunk = tid & 3, tl = tid >> 2;
+  unsigned voff[16];
+  {
+    const int t = t0 + tl;
+    const bool tv = t < p.ntiles;
+    const int n = t / tpi;
+    const int rem = t - n * tpi;
+    const int th = rem / p.TW;
+    const int tw = rem - th * p.TW;
+    const int h0 = 2 * th - 1, w0 = 2 * tw - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int hi = h0 + r, wi = w0 + c;
+        const bool ok = tv && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        voff[r * 4 + c] = ok ? (unsigned)((((n * p.H + hi) * p.W + wi) * p.ldx + chunk * 4) * 4) : OOB;
+      }
+  }
+  float4 d[16];
+  auto load_patch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[i], kt * (WK * 4), 0));
+  };
+  float* vdst = smem + tl * VLD + chunk * 4;
+  auto transform_store = [&]() {
+    float4 t[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {            // Bt . d   (rows)
+      t[0 + c] = sub4(d[0 + c], d[8 + c]);
+      t[4 + c] = add4(d[4 + c], d[8 + c]);
+      t[8 + c] = sub4(d[8 + c], d[4 + c]);
+      t[12 + c] = sub4(d[4 + c], d[12 + c]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {            // . B      (columns)
+      const float4 v0 = sub4(t[i * 4 + 0], t[i * 4 + 2]);
+      const float4 v1 = add4(t[i * 4 + 1], t[i * 4 + 2]);
+      const float4 v2 = sub4(t[i * 4 + 2], t[i * 4 + 1]);
+      const float4 v3 = sub4(t[i * 4 + 1], t[i * 4 + 3]);
+      *reinterpret_cast<float4*>(vdst + (i * 4 + 0) * (WT * VLD)) = v0;
+      *reinterpret_cast<float4*>(vdst + (i * 4 + 1) * (WT * VLD)) = v1;
+      *reinterpret_cast<float4*>(vdst + (i * 4 + 2) * (WT * VLD)) = v2;
+      *reinterpret_cast<float4*>(vdst + (i * 4 + 3) * (WT * VLD)) = v3;
+    }
+  };
+
+  // ---- MFMA role: wave wv owns xi = 4 wv + j ----
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][mb][nb][e] = 0.f;
+
+  const float* a_frag0 = smem + (4 * wv * WT + (lane & 31)) * VLD + (lane >> 5) * 4;
+  const unsigned b_voff = (unsigned)lane * 16u;
+  float4 bq[2][4][2];
+  // packed U: [tile_n][kt][xi][nb][g] chunks of 1 KiB (64 lanes x float4)
+  auto load_b = [&](float4 (&dst)[4][2], int kt, int g) {
+    const int base = ((((tile_n * p.nk + kt) * 16 + 4 * wv) * 2) * 2 + g) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        dst[j][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, base + (j * 4 + nb * 2) * 1024, 0));
+  };
+
+  load_patch(0);
+  load_b(bq[0], 0, 0);
+  for (int kt = 0; kt < p.nk; ++kt) {
+    transform_store();
+    __syncthreads();
+    if (kt + 1 < p.nk) load_patch(kt + 1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float4 a[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+          a[j][mb] = *reinterpret_cast<const float4*>(a_frag0 + (j * WT + mb * 32) * VLD + g * 8);
+      // prefetch the next 8-channel group's weight fragments (clamped at the end: harmless re-read)
+      if (g == 0) {
+        load_b(bq[1], kt, 1);
+      } else {
+        load_b(bq[0], kt + 1 < p.nk ? kt + 1 : kt, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              acc[j][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[j][mb], s), comp(bq[g][j][nb], s), acc[j][mb][nb], 0, 0, 0);
+    }
+    __syncthreads();     // every wave is done reading V before the next transform overwrites it
+  }
+
+  // ---- epilogue ----
+  // Y = At M A with At = [[1,1,1,0],[0,1,-1,-1]].  This wave holds row i = wv of M (its four xi are the
+  // columns j): fold the columns first, Z[i][b] = sum_j M[i][j] At[b][j], then meet the other rows in LDS.
+  // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+  float* zs = smem;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int col = nb * 32 + (lane & 31);
+        const float m0 = acc[0][mb][nb][e], m1 = acc[1][mb][nb][e], m2 = acc[2][mb][nb][e], m3 = acc[3][mb][nb][e];
+        zs[((wv * 2 + 0) * WT + row) * ZLD + col] = m0 + m1 + m2;
+        zs[((wv * 2 + 1) * WT + row) * ZLD + col] = m1 - m2 - m3;
+      }
+  __syncthreads();
+  const int c4 = tid & 15, ts = tid >> 4;
+  const int co = n0 + c4 * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int tile = pass * 16 + ts;
+    const int t = t0 + tile;
+    if (t >= p.ntiles) continue;
+    const int n = t / tpi;
+    const int rem = t - n * tpi;
+    const int th = rem / p.TW;
+    const int tw = rem - th * p.TW;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int wo = 2 * tw + b;
+      if (wo >= p.W) continue;
+      const float4 z0 = *reinterpret_cast<const float4*>(&zs[((0 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
+      const float4 z1 = *reinterpret_cast<const float4*>(&zs[((1 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
+      const float4 z2 = *reinterpret_cast<const float4*>(&zs[((2 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
+      const float4 z3 = *reinterpret_cast<const float4*>(&zs[((3 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ho = 2 * th + a;
+        if (ho >= p.H) continue;
+        float4 v = a == 0 ? add4(add4(z0, z1), z2) : sub4(sub4(z1, z2), z3);
+        v = add4(v, bv);
+        if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const long m = ((long)n * p.H + ho) * p.W + wo;
+        if (p.res_mode == 1) {
+          const float4 r = *reinterpret_cast<const float4*>(p.res + m * p.ldr + co);
+          v = add4(v, r);
+        }
+        if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(p.y + m * p.ldy + p.ycoff + co) = v;
+      }
+    }
+  }
+}
+
+// U = G g G^t per (cout, cin), written in the fragment order the kernel streams:
+// [cout/64][cin/16][xi][nb][g][lane][s]  with  cout = 64 tn + 32 nb + (lane&31),  cin = 16 kt + 8 g + 4 (lane>>5) + s
+__global__ void wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
+  const long total = 16L * Cout * Cin;
+  const int nk = Cin / WK;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    long r = o;
+    const int s = (int)(r & 3); r >>= 2;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int g = (int)(r & 1); r >>= 1;
+    const int nb = (int)(r & 1); r >>= 1;
+    const int xi = (int)(r & 15); r >>= 4;
+    const int kt = (int)(r % nk);
+    const int tn = (int)(r / nk);
+    const int co = tn * WN + nb * 32 + (lane & 31);
+    const int ci = kt * WK + g * 8 + (lane >> 5) * 4 + s;
+    const int i = xi >> 2, j = xi & 3;
+    const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc += G[i][a] * G[j][b] * (double)w[(((long)co * 3 + a) * 3 + b) * Cin + ci];
+    u[o] = (float)acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int glass_winograd_supported(const glass_conv_desc* d) {
+  if (!d) return 0;
+  const long xb = (long)d->N * d->H * d->W * d->ldx * 4;
+  return d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+         d->Cin % WK == 0 && d->Cout % WN == 0 && d->ldx % 4 == 0 && d->y_cstride == 1 && d->ldy % 4 == 0 &&
+         d->y_coff % 4 == 0 && (d->res_mode == 0 || (d->res_mode == 1 && d->ldr % 4 == 0)) && xb < 0x7fffff00L &&
+         d->Ho == d->H && d->Wo == d->W;
+}
+
+extern "C" size_t glass_winograd_weight_floats(int Cout, int Cin) { return (size_t)16 * (size_t)Cout * (size_t)Cin; }
+
+extern "C" int glass_winograd_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream) {
+  GLASS_CHECK_ARG(w && u_packed, "glass_winograd_pack_weights: null pointer");
+  GLASS_CHECK_ARG(Cout > 0 && Cin > 0 && Cout % WN == 0 && Cin % WK == 0,
+                  "glass_winograd_pack_weights: Cout=%d must be a multiple of 64 and Cin=%d a multiple of 16", Cout, Cin);
+  const long total = 16L * Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(wino_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u_packed, Cout, Cin);
+  GLASS_CHECK_LAUNCH("glass_winograd_pack_weights");
+  return GLASS_OK;
+}
+
+extern "C" int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
+                                           const float* bias, const float* residual, float* y, glass_stream_t stream) {
+  GLASS_CHECK_ARG(d && x && u_packed && y, "glass_conv3x3_winograd_nhwc: null pointer");
+  GLASS_CHECK_ARG(glass_winograd_supported(d),
+                  "glass_conv3x3_winograd_nhwc: needs 3x3/stride 1/pad 1, Cin%%16==0, Cout%%64==0, unit channel stride, "
+                  "res_mode 0/1 and x < 2 GiB (got Cin=%d Cout=%d k=%dx%d s=%d p=%d)", d->Cin, d->Cout, d->KH, d->KW,
+                  d->stride_h, d->pad_h);
+  GLASS_CHECK_ARG(d->res_mode == 0 || residual != nullptr, "glass_conv3x3_winograd_nhwc: res_mode set but residual is null");
+  GLASS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)u_packed & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                      (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (residual == nullptr || ((uintptr_t)residual & 15) == 0),
+                  "glass_conv3x3_winograd_nhwc: pointers must be 16-byte aligned");
+  if (d->N == 0) return GLASS_OK;
+  WinoParams p;
+  p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+  p.TH = (d->H + 1) / 2; p.TW = (d->W + 1) / 2;
+  const long nt = (long)d->N * p.TH * p.TW;
+  GLASS_CHECK_ARG(nt < 0x7fffffffL, "glass_conv3x3_winograd_nhwc: too many tiles");
+  p.ntiles = (int)nt;
+  p.nk = d->Cin / WK;
+  p.ldx = d->ldx; p.ldy = d->ldy; p.ycoff = d->y_coff; p.ldr = d->ldr; p.relu = d->relu; p.res_mode = d->res_mode;
+  p.tiles_m = cdiv(p.ntiles, WT);
+  p.tiles_n = d->Cout / WN;
+  p.x_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldx * 4);
+  p.u_bytes = (unsigned)(16L * d->Cout * d->Cin * 4);
+  const long nblk = (long)p.tiles_m * p.tiles_n;
+  GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv3x3_winograd_nhwc: bad grid");
+  static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_f32),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES);
+  if (attr_rc != 0) {
+    glass_set_error("glass_conv3x3_winograd_nhwc: cannot reserve %d bytes of LDS (hip error %d)", WINO_LDS_BYTES, attr_rc);
+    return GLASS_EHIP;
+  }
+  hipLaunchKernelGGL(conv3x3_wino_f32, dim3((unsigned)nblk), dim3(256), WINO_LDS_BYTES, (hipStream_t)stream, p);
+  GLASS_CHECK_LAUNCH("glass_conv3x3_winograd_nhwc");
+  return GLASS_OK;
+}

@@ -5,8 +5,10 @@ CPU tensors: there is no fallback path.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -60,11 +62,52 @@ def conv_out_size(H, W, KH, KW, stride, padding):
     return (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
 
 
+# Winograd F(2x2,3x3) weights, packed once per weight tensor (glass_winograd_pack_weights) the first time a
+# 3x3/stride-1 layer runs.  Keyed by the weight's storage address; the entry pins the weight tensor so the
+# address cannot be recycled, and is re-packed if the tensor was modified in place (_version).
+_WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": collections.OrderedDict(), "max": 512}
+
+
+def set_winograd(enabled: bool) -> bool:
+    """Route eligible 3x3 convolutions through glass_conv3x3_winograd_nhwc (default on; GLASS_WINOGRAD=0 turns
+    it off).  Returns the previous setting."""
+    prev = _WINO["enabled"]
+    _WINO["enabled"] = bool(enabled)
+    return prev
+
+
+def winograd_pack(w: torch.Tensor) -> torch.Tensor:
+    """w [Cout,3,3,Cin] -> packed U (16*Cout*Cin floats) for glass_conv3x3_winograd_nhwc."""
+    _f32c(w, "w")
+    Cout, KH, KW, Cin = w.shape
+    n = int(lib().glass_winograd_weight_floats(Cout, Cin))
+    u = torch.empty((n,), dtype=torch.float32, device=w.device)
+    check(lib().glass_winograd_pack_weights(c_void_p(_dev(w, "w")), Cout, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())),
+          "glass_winograd_pack_weights")
+    return u
+
+
+def _winograd_weights(w: torch.Tensor) -> torch.Tensor:
+    cache = _WINO["cache"]
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = cache.get(key)
+    if ent is not None and ent[0] is w and ent[2] == w._version:
+        cache.move_to_end(key)
+        return ent[1]
+    u = winograd_pack(w)
+    cache[key] = (w, u, w._version)
+    if len(cache) > _WINO["max"]:
+        cache.popitem(last=False)
+    return u
+
+
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride=1, padding=0,
                 relu: int = 0, residual: Optional[torch.Tensor] = None, res_mode: int = 0,
                 out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cstride: int = 1,
-                cin: Optional[int] = None) -> torch.Tensor:
-    """y = act(conv(x, w) + bias [+ residual]).  x [N,H,W,ldx] NHWC, w [Cout,KH,KW,Cin]."""
+                cin: Optional[int] = None, winograd: Optional[bool] = None) -> torch.Tensor:
+    """y = act(conv(x, w) + bias [+ residual]).  x [N,H,W,ldx] NHWC, w [Cout,KH,KW,Cin].
+    3x3/stride 1/pad 1 layers that glass_winograd_supported() accepts go through the Winograd kernel
+    (winograd=None: follow set_winograd(); True/False force it for this call)."""
     _f32c(x, "x"); _f32c(w, "w")
     N, H, W, ldx = x.shape
     Cout, KH, KW, Cin = w.shape
@@ -83,6 +126,17 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                  res_mode if residual is not None else 0, residual.shape[-1] if residual is not None else 0)
     if residual is not None:
         _f32c(residual, "residual")
+    use_wino = _WINO["enabled"] if winograd is None else winograd
+    if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
+        u = _winograd_weights(w)
+        check(lib().glass_conv3x3_winograd_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
+                                                c_void_p(_dev(bias, "bias") if bias is not None else None),
+                                                c_void_p(_dev(residual, "residual") if residual is not None else None),
+                                                c_void_p(_dev(out, "out")), c_void_p(stream_handle())),
+              "glass_conv3x3_winograd_nhwc")
+        return out
+    if winograd:
+        raise GlassLibraryError("winograd=True but glass_winograd_supported() rejects this layer")
     check(lib().glass_conv2d_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
                                   c_void_p(_dev(bias, "bias") if bias is not None else None),
                                   c_void_p(_dev(residual, "residual") if residual is not None else None),

@@ -19,6 +19,7 @@
 #ifndef GLASS_HIP_H
 #define GLASS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -62,6 +63,23 @@ typedef struct glass_conv_desc {
 
 int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
                       const float* residual, float* y, glass_stream_t stream);
+
+/* Winograd F(2x2,3x3) form of the same operator for the 3x3 / stride 1 / pad 1 layers (FPN output convs,
+ * RPN head conv, every 3x3 of the ResNet trunk and of the local extractor's BasicBlocks, fusion output
+ * conv): 2.25x fewer fp32 MFMA multiplies, results equal to glass_conv2d_nhwc to fp32 rounding
+ * (|diff| <~ 1e-5 of the output scale; tests/test_gpu_ops.py).  Same descriptor, epilogue semantics and
+ * error behaviour as glass_conv2d_nhwc; `u_packed` replaces `w`:
+ *   glass_winograd_supported(d)            1 if the descriptor can take this path (3x3 s1 p1, Cin % 16 == 0,
+ *                                          Cout % 64 == 0, y_cstride == 1, ldy/y_coff % 4 == 0, res_mode 0/1,
+ *                                          input < 2 GiB), else 0 - callers fall back to glass_conv2d_nhwc.
+ *   glass_winograd_weight_floats(Cout,Cin) floats in the packed buffer (16 * Cout * Cin).
+ *   glass_winograd_pack_weights            w [Cout][3][3][Cin] (BN-folded) -> U = G w G^t in the kernel's
+ *                                          MFMA fragment order; run once per layer at checkpoint load.     */
+int glass_winograd_supported(const glass_conv_desc* d);
+size_t glass_winograd_weight_floats(int Cout, int Cin);
+int glass_winograd_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream);
+int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
+                                const float* residual, float* y, glass_stream_t stream);
 
 /* max pooling NHWC (d2 stem max_pool2d k3 s2 p1; local extractor maxpool1..3,
  * glass/modeling/fusion/local_feature_extraction.py:112,118,124). Padding acts as -inf. */

@@ -28,19 +28,33 @@ LAYERS = [
     ("fc1 800x12544->2048", 800, 1, 1, 12544, 2048, 1, 1, 0),
     ("rpn p6 3x3 256 @16", 8, 16, 16, 256, 256, 3, 1, 1),
 ]
+def timed(fn, it=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+
+
+only = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, N, H, W, Cin, Cout, k, s, p in LAYERS:
+    if only and only not in name:
+        continue
     x = torch.randn((N, H, W, Cin), device=dev)
     w = torch.randn((Cout, k, k, Cin), device=dev) * 0.05
     b = torch.randn((Cout,), device=dev)
-    y = K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    it = 5
-    e0.record()
-    for _ in range(it):
-        K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / it
+    y = K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, winograd=False)
+    ms = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y, winograd=False))
     flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * Cin * k * k
-    print(f"{name:36s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    line = f"{name:36s} direct {ms:8.3f} ms {flops / ms / 1e9:7.1f} TFLOP/s"
+    d = K.ConvDesc(N, H, W, Cin, Cout, k, k, s, s, p, p, y.shape[1], y.shape[2], Cin, Cout, 0, 1, 1, 0, 0)
+    if k == 3 and K.lib().glass_winograd_supported(K.ctypes.byref(d)):
+        y2 = torch.empty_like(y)
+        msw = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y2, winograd=True))
+        err = float((y2 - y).abs().max() / y.abs().max())
+        line += f" | winograd {msw:8.3f} ms {flops / msw / 1e9:7.1f} TFLOP/s-equivalent  x{ms / msw:.2f}  rel.err {err:.1e}"
+    print(line, flush=True)

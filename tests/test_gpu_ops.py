@@ -34,6 +34,71 @@ CONV_CASES = [
 ]
 
 
+WINO_CASES = [
+    # N, H, W, Cin, Cout, relu, residual, (ld_out, coff)
+    (1, 2, 2, 16, 64, 0, False, None),            # a single tile
+    (3, 16, 33, 256, 256, 1, True, None),         # local extractor layer3 shape: odd width, ragged last block
+    (2, 15, 21, 64, 64, 2, True, None),           # odd height and width, ReLU before the residual add
+    (1, 64, 64, 128, 128, 1, False, None),
+    (5, 8, 32, 512, 256, 0, False, (512, 256)),   # fusion output conv writing into a wider buffer
+    (2, 7, 5, 32, 192, 1, True, None),            # three channel blocks, tiny image
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_matches_direct_and_torch(case):
+    """glass_conv3x3_winograd_nhwc vs glass_conv2d_nhwc (same fp32 MFMA, different algebra) and vs torch CPU fp64.
+    Tolerance: F(2x2,3x3) in fp32 adds a few ulp of the INPUT transform's scale; 2e-5 of the output range."""
+    from glass_amd.ops import native as K
+    N, H, W, Cin, Cout, relu, use_res, strided = case
+    dev = _dev()
+    x = _rand((N, Cin, H, W), 11)
+    w = _rand((Cout, Cin, 3, 3), 12, (2.0 / (Cin * 9)) ** 0.5)
+    b = _rand((Cout,), 13, 0.1)
+    res = _rand((N, Cout, H, W), 14) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu == 2:
+        ref = F.relu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    if relu == 1:
+        ref = F.relu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
+    kw = dict(padding=1, relu=relu, residual=rd, res_mode=1 if rd is not None else 0)
+    if strided is None:
+        yw = K.conv2d_nhwc(xd, wd, b.to(dev), winograd=True, **kw)
+        yd = K.conv2d_nhwc(xd, wd, b.to(dev), winograd=False, **kw)
+    else:
+        ld, coff = strided
+        bufw = torch.full((N, H, W, ld), 7.0, device=dev)
+        bufd = torch.full((N, H, W, ld), 7.0, device=dev)
+        K.conv2d_nhwc(xd, wd, b.to(dev), winograd=True, out=bufw, out_coff=coff, **kw)
+        K.conv2d_nhwc(xd, wd, b.to(dev), winograd=False, out=bufd, out_coff=coff, **kw)
+        torch.cuda.synchronize()
+        assert float((bufw[..., :coff] - 7.0).abs().max()) == 0.0      # untouched channels stay untouched
+        yw, yd = bufw[..., coff:coff + Cout], bufd[..., coff:coff + Cout]
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    got_w = yw.cpu().permute(0, 3, 1, 2).double()
+    got_d = yd.cpu().permute(0, 3, 1, 2).double()
+    assert float((got_w - ref).abs().max()) <= 2e-5 * scale
+    assert float((got_d - ref).abs().max()) <= 2e-5 * scale
+    assert float((got_w - got_d).abs().max()) <= 2e-5 * scale
+
+
+def test_winograd_rejects_unsupported():
+    from glass_amd.ops import native as K
+    from glass_amd._lib import GlassLibraryError
+    dev = _dev()
+    x = torch.zeros((1, 8, 8, 16), device=dev)
+    w = torch.zeros((32, 3, 3, 16), device=dev)       # Cout % 64 != 0
+    with pytest.raises(GlassLibraryError):
+        K.conv2d_nhwc(x, w, None, padding=1, winograd=True)
+    K.conv2d_nhwc(x, w, None, padding=1)              # default: silently the direct kernel
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_matches_torch(case):
     from glass_amd.ops import native as K
