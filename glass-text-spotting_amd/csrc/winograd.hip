@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
   for (int kt = 0; kt < p.nk; ++kt) {
     transform_store();
     __syncthreads();
-    if (kt + 1 < p.nk) load_patch(kt + 1);
+    const int ktn = kt + 1 < p.nk ? kt + 1 : kt;     // clamped at the end: a harmless re-read keeps the loop one block
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       float4 a[4][2];
@@ -165,11 +165,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
           a[j][mb] = *reinterpret_cast<const float4*>(a_frag0 + (j * WT + mb * 32) * VLD + g * 8);
-      // prefetch the next 8-channel group's weight fragments (clamped at the end: harmless re-read)
+      // prefetches: the next 8-channel group's weight fragments first (needed 64 MFMAs from now), then
+      // (g == 0) the next k-tile's patch (needed at the next transform)
       if (g == 0) {
         load_b(bq[1], kt, 1);
+        load_patch(ktn);
       } else {
-        load_b(bq[0], kt + 1 < p.nk ? kt + 1 : kt, 0);
+        load_b(bq[0], ktn, 0);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -180,6 +182,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
               acc[j][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[j][mb], s), comp(bq[g][j][nb], s), acc[j][mb][nb], 0, 0, 0);
+      // Issue pattern.  A burst of vector-memory instructions fills the CU's address queue and the wave then
+      // sits on the next load instead of issuing its next MFMA (all four waves burst together right after the
+      // barrier), so the loads are metered out between MFMAs: one load per 2-3 MFMAs (128-192 cycles).
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);          // the 8 A-fragment LDS reads
+      if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                              // weight fragments of g = 1
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                             // next patch
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                              // weight fragments of the next k-tile
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+      }
     }
     __syncthreads();     // every wave is done reading V before the next transform overwrites it
   }
