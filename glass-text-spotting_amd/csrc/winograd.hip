@@ -36,11 +36,11 @@ namespace {
 constexpr int WT = 64;                        // output tiles (2x2 pixels each) per block
 constexpr int WN = 64;                        // output channels per block
 constexpr int WK = 16;                        // input channels per k-tile
-constexpr int VLD = WK + 4;                   // padded V row (conflict-free ds_read_b128, see conv.hip)
+constexpr int VROW = WK;                      // unpadded V row (64 B); 16-byte slots are XOR-swizzled instead
 constexpr int ZLD = WN + 4;
-constexpr int V_FLOATS = 16 * WT * VLD;       // 80 KiB
+constexpr int V_FLOATS = 16 * WT * VROW;      // 64 KiB per stage, two stages
 constexpr int Z_FLOATS = 4 * 2 * WT * ZLD;    // 136 KiB
-constexpr int WINO_LDS_BYTES = (V_FLOATS > Z_FLOATS ? V_FLOATS : Z_FLOATS) * 4;
+constexpr int WINO_LDS_BYTES = (2 * V_FLOATS > Z_FLOATS ? 2 * V_FLOATS : Z_FLOATS) * 4;
 constexpr unsigned OOB = 0x7fffffffu;
 
 struct WinoParams {
@@ -98,33 +98,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
         voff[r * 4 + c] = ok ? (unsigned)((((n * p.H + hi) * p.W + wi) * p.ldx + chunk * 4) * 4) : OOB;
       }
   }
-  float4 d[16];
+  float4 d[16], t[16];
+  auto load_patch1 = [&](int kt, int i) {
+    d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[i], kt * (WK * 4), 0));
+  };
   auto load_patch = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[i], kt * (WK * 4), 0));
+    for (int i = 0; i < 16; ++i) load_patch1(kt, i);
   };
-  float* vdst = smem + tl * VLD + chunk * 4;
-  auto transform_store = [&]() {
-    float4 t[16];
+  // V[stage][xi][tile][16]: a row is 64 bytes, so four consecutive rows span the 64 banks once; XOR-ing the
+  // 16-byte slot with (tile/4)%4 spreads the 16 rows a ds_read_b128 service group touches over all 16 slots.
+  float* vdst = smem + tl * VROW + ((chunk ^ ((tl >> 2) & 3)) * 4);
+  // Bt d B in 20 pieces so that the main loop can meter it out between MFMAs:
+  auto row_piece = [&](int c) {              // t[.][c] = Bt . d[.][c]
+    t[0 + c] = sub4(d[0 + c], d[8 + c]);
+    t[4 + c] = add4(d[4 + c], d[8 + c]);
+    t[8 + c] = sub4(d[8 + c], d[4 + c]);
+    t[12 + c] = sub4(d[4 + c], d[12 + c]);
+  };
+  auto col_piece = [&](int stage, int i, int j) {   // V[i][j] = (t . B)[i][j]  -> LDS
+    const float4 v = j == 0 ? sub4(t[i * 4 + 0], t[i * 4 + 2]) : j == 1 ? add4(t[i * 4 + 1], t[i * 4 + 2])
+                   : j == 2 ? sub4(t[i * 4 + 2], t[i * 4 + 1]) : sub4(t[i * 4 + 1], t[i * 4 + 3]);
+    *reinterpret_cast<float4*>(vdst + stage * V_FLOATS + (i * 4 + j) * (WT * VROW)) = v;
+  };
+  auto transform_store = [&](int stage) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {            // Bt . d   (rows)
-      t[0 + c] = sub4(d[0 + c], d[8 + c]);
-      t[4 + c] = add4(d[4 + c], d[8 + c]);
-      t[8 + c] = sub4(d[8 + c], d[4 + c]);
-      t[12 + c] = sub4(d[4 + c], d[12 + c]);
-    }
+    for (int c = 0; c < 4; ++c) row_piece(c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {            // . B      (columns)
-      const float4 v0 = sub4(t[i * 4 + 0], t[i * 4 + 2]);
-      const float4 v1 = add4(t[i * 4 + 1], t[i * 4 + 2]);
-      const float4 v2 = sub4(t[i * 4 + 2], t[i * 4 + 1]);
-      const float4 v3 = sub4(t[i * 4 + 1], t[i * 4 + 3]);
-      *reinterpret_cast<float4*>(vdst + (i * 4 + 0) * (WT * VLD)) = v0;
-      *reinterpret_cast<float4*>(vdst + (i * 4 + 1) * (WT * VLD)) = v1;
-      *reinterpret_cast<float4*>(vdst + (i * 4 + 2) * (WT * VLD)) = v2;
-      *reinterpret_cast<float4*>(vdst + (i * 4 + 3) * (WT * VLD)) = v3;
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) col_piece(stage, i, j);
   };
 
   // ---- MFMA role: wave wv owns xi = 4 wv + j ----
@@ -138,74 +141,74 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][mb][nb][e] = 0.f;
 
-  const float* a_frag0 = smem + (4 * wv * WT + (lane & 31)) * VLD + (lane >> 5) * 4;
+  const int a_sw = ((lane & 31) >> 2) & 3;
+  const float* a_frag_g0 = smem + (4 * wv * WT + (lane & 31)) * VROW + (((lane >> 5)) ^ a_sw) * 4;
+  const float* a_frag_g1 = smem + (4 * wv * WT + (lane & 31)) * VROW + ((2 + (lane >> 5)) ^ a_sw) * 4;
   const unsigned b_voff = (unsigned)lane * 16u;
   float4 bq[2][4][2];
   // packed U: [tile_n][kt][xi][nb][g] chunks of 1 KiB (64 lanes x float4)
-  auto load_b = [&](float4 (&dst)[4][2], int kt, int g) {
+  auto load_b1 = [&](float4 (&dst)[4][2], int kt, int g, int idx) {
     const int base = ((((tile_n * p.nk + kt) * 16 + 4 * wv) * 2) * 2 + g) * 1024;
+    const int j = idx >> 1, nb = idx & 1;
+    dst[j][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, base + (j * 4 + nb * 2) * 1024, 0));
+  };
+  auto load_b = [&](float4 (&dst)[4][2], int kt, int g) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-        dst[j][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, base + (j * 4 + nb * 2) * 1024, 0));
+    for (int idx = 0; idx < 8; ++idx) load_b1(dst, kt, g, idx);
   };
 
+  // Software pipeline (one barrier per k-tile, V double buffered):
+  //   g = 0 of k-tile kt:  MFMAs on V[kt&1]  ||  weight fragments for g = 1  ||  Bt d B of patch kt+1 -> V[(kt+1)&1]
+  //                                            ||  then the patch loads of k-tile kt+2
+  //   g = 1 of k-tile kt:  MFMAs on V[kt&1]  ||  weight fragments for kt+1
+  // A burst of vector-memory instructions fills the CU's address queue and the wave then sits on its next
+  // load instead of issuing the next MFMA (all four waves burst together after the barrier), so the loads,
+  // the transform's VALU work and its LDS writes are metered out between the MFMAs: the source below IS
+  // the issue order, pinned chunk by chunk with sched_barrier(0).
   load_patch(0);
   load_b(bq[0], 0, 0);
+  transform_store(0);
+  load_patch(p.nk > 1 ? 1 : 0);
+  __syncthreads();
   for (int kt = 0; kt < p.nk; ++kt) {
-    transform_store();
-    __syncthreads();
-    const int ktn = kt + 1 < p.nk ? kt + 1 : kt;     // clamped at the end: a harmless re-read keeps the loop one block
+    const int cur = kt & 1;
+    const int ktn = kt + 1 < p.nk ? kt + 1 : kt;     // clamped at the end: harmless re-reads keep the loop one block
+    const int ktnn = kt + 2 < p.nk ? kt + 2 : kt;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+      const float* af = (g == 0 ? a_frag_g0 : a_frag_g1) + cur * V_FLOATS;
       float4 a[4][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
-          a[j][mb] = *reinterpret_cast<const float4*>(a_frag0 + (j * WT + mb * 32) * VLD + g * 8);
-      // prefetches: the next 8-channel group's weight fragments first (needed 64 MFMAs from now), then
-      // (g == 0) the next k-tile's patch (needed at the next transform)
-      if (g == 0) {
-        load_b(bq[1], kt, 1);
-        load_patch(ktn);
-      } else {
-        load_b(bq[0], ktn, 0);
+          a[j][mb] = *reinterpret_cast<const float4*>(af + (j * WT + mb * 32) * VROW);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        // side work issued BEFORE MFMA m
+        if (m < 16) {
+          if ((m & 1) == 0) {                                   // 8 weight-fragment loads, one per 2 MFMAs
+            if (g == 0) load_b1(bq[1], kt, 1, m >> 1); else load_b1(bq[0], ktn, 0, m >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else if (g == 0) {
+          // transform of patch kt+1: 4 row pieces (every 3rd MFMA from 16), then 16 column pieces (every 2nd from 28)
+          if (m < 28) {
+            if ((m - 16) % 3 == 0) { row_piece((m - 16) / 3); __builtin_amdgcn_sched_barrier(0); }
+          } else if (m < 60) {
+            const int q = (m - 28) >> 1;
+            if (((m - 28) & 1) == 0) col_piece(cur ^ 1, q >> 2, q & 3);
+            else load_patch1(ktnn, q);            // d is free again: patch of k-tile kt+2, a whole g ahead of its use
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        const int s_ = m >> 4, j = (m >> 2) & 3, mb = (m >> 1) & 1, nb = m & 1;
+        acc[j][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[j][mb], s_), comp(bq[g][j][nb], s_), acc[j][mb][nb], 0, 0, 0);
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-              acc[j][mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[j][mb], s), comp(bq[g][j][nb], s), acc[j][mb][nb], 0, 0, 0);
-      // Issue pattern.  A burst of vector-memory instructions fills the CU's address queue and the wave then
-      // sits on the next load instead of issuing its next MFMA (all four waves burst together right after the
-      // barrier), so the loads are metered out between MFMAs: one load per 2-3 MFMAs (128-192 cycles).
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);          // the 8 A-fragment LDS reads
-      if (g == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {                              // weight fragments of g = 1
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {                             // next patch
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {                              // weight fragments of the next k-tile
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-        }
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();     // every wave is done reading V before the next transform overwrites it
+    __syncthreads();     // V[cur] fully read, V[cur^1] fully written
   }
 
   // ---- epilogue ----
