@@ -55,14 +55,15 @@ def parse():
 
 
 class ConvMeter:
-    """Wraps glass_conv2d_nhwc launches with HIP events on the launch stream (torch's current
-    stream = the stream every kernel of the path is enqueued on) and tallies algorithmic FLOPs."""
+    """Wraps the conv launches (glass_conv2d_nhwc / glass_conv3x3_winograd_nhwc) with HIP events on the launch
+    stream (torch's current stream = the stream every kernel of the path is enqueued on) and tallies, per
+    kernel family, the ALGORITHMIC FLOPs (direct-convolution count) and the FLOPs the
+    kernel actually issues to the matrix cores (Winograd F(2x2,3x3): 16 instead of 36 MACs per 2x2 tile)."""
 
     def __init__(self, K):
         self.K = K
         self.orig = K.conv2d_nhwc
-        self.events = []
-        self.flops = 0.0
+        self.fam = {"winograd": {"events": [], "algo": 0.0, "exec": 0.0}, "direct": {"events": [], "algo": 0.0, "exec": 0.0}}
 
     def __enter__(self):
         def wrapped(x, w, bias=None, **kw):
@@ -72,8 +73,14 @@ class ConvMeter:
             e1.record()
             cout, kh, kw_, cin = w.shape
             cin_real = 3 if cin == 4 else cin           # NHWC4-padded RGB inputs
-            self.flops += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin_real
-            self.events.append((e0, e1))
+            algo = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin_real
+            f = self.fam[self.K.last_conv_path()]
+            f["algo"] += algo
+            if self.K.last_conv_path() == "winograd":   # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
+                f["exec"] += 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2) * 16 * cout * cin
+            else:
+                f["exec"] += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin
+            f["events"].append((e0, e1))
             return y
         self.K.conv2d_nhwc = wrapped
         return self
@@ -81,9 +88,13 @@ class ConvMeter:
     def __exit__(self, *a):
         self.K.conv2d_nhwc = self.orig
 
-    def total_ms(self):
+    def summary(self):
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self.events)
+        out = {}
+        for name, f in self.fam.items():
+            ms = sum(a.elapsed_time(b) for a, b in f["events"])
+            out[name] = {"launches": len(f["events"]), "ms": ms, "algo_flops": f["algo"], "exec_flops": f["exec"]}
+        return out
 
 
 def cpu_baseline(cfg, sd, side, rois):
@@ -197,19 +208,40 @@ def main():
         model.roi_heads.two_stream_local = False
         with ConvMeter(K) as meter:
             local_step()
-            conv_ms = meter.total_ms()
-            n_launch = len(meter.events)
-            conv_flops = meter.flops
+            fam = meter.summary()
         model.roi_heads.two_stream_local = two
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant instantiation from the PMC passes kept under profiles/
-        # (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs, gfx950 x2 read correction applied)
-        traffic, mfma_util = None, None
+        conv_ms = sum(f["ms"] for f in fam.values())
+        conv_flops = sum(f["algo_flops"] for f in fam.values())
+        n_launch = sum(f["launches"] for f in fam.values())
+        KNAME = {"winograd": "conv3x3_wino_f32 (Winograd F(2x2,3x3), fp32 MFMA)",
+                 "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)"}
+        PKEY = {"winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_128x128"}
+        dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time
+        # PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate
+        # rocprofv3 --pmc runs, gfx950 x2 read correction applied; scripts/pmc_make_summary.py)
+        pmc_all = {}
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_summary.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                pj = json.load(f)
-            traffic, mfma_util = pj.get("hbm_bytes_per_launch_corrected"), pj.get("MfmaUtil_percent")
+                pmc_all = json.load(f)
+
+        def fam_entry(k):
+            f = fam[k]
+            if f["launches"] == 0:
+                return None
+            sec = f["ms"] * 1e-3
+            pj = pmc_all.get(PKEY[k], {}) if isinstance(pmc_all.get(PKEY[k], {}), dict) else {}
+            return {"kernel": KNAME[k], "launches_per_step": f["launches"], "kernel_ms_per_step": f["ms"],
+                    "avg_launch_ms": f["ms"] / f["launches"],
+                    "executed_tflops": f["exec_flops"] / sec / 1e12, "executed_frac": f["exec_flops"] / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "algorithmic_tflops": f["algo_flops"] / sec / 1e12,
+                    "algorithmic_frac": f["algo_flops"] / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "algorithmic_gflop_per_launch": f["algo_flops"] / f["launches"] / 1e9,
+                    "traffic": pj.get("hbm_bytes_per_launch_corrected"), "mfma_util_percent_pmc": pj.get("MfmaUtil_percent")}
+
+        ent = fam_entry(dom)
+        other = [fam_entry(k) for k in fam if k != dom and fam[k]["launches"]]
+        achieved = ent["executed_tflops"]
         line = {
             "metric": "images/sec/GPU end-to-end spotting, 1000x1000, ~32 RoIs; 1/2/4/8 GPU scaling",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,14 +255,24 @@ def main():
                        "weights": "random-init (seed 1234), reference architecture",
                        "parallelism": f"image-shard x{world}, 1 all_gather of result records/step"},
             "images_per_sec_per_gpu": value / world,
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
+            "roofline": {"bound": "mfma", "kernel": ent["kernel"],
+                         # `achieved` counts the multiplies the kernel really issues to the matrix cores, so that
+                         # frac is a hardware-utilisation figure <= 1; the direct-convolution ("algorithmic",
+                         # SURVEY 8d) rate of the same launches is reported beside it and exceeds the MFMA peak
+                         # when the kernel is the Winograd one (2.25x fewer multiplies per output).
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes/launch, PMC (profiles/r01_pmc_conv_summary.json), 128x128 instantiation",
-                         "mfma_util_percent_pmc": mfma_util,
-                         "launches_per_step": n_launch, "algorithmic_gflop_per_launch": conv_flops / n_launch / 1e9,
-                         "avg_launch_ms": conv_ms / n_launch, "kernel_ms_per_step": conv_ms,
-                         "share_of_step": conv_ms / ms_per_step},
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "algorithmic_achieved": ent["algorithmic_tflops"], "algorithmic_frac": ent["algorithmic_frac"],
+                         "traffic": ent["traffic"],
+                         "traffic_note": "HBM bytes/launch of this kernel, PMC (profiles/r01_pmc_conv_summary.json)",
+                         "mfma_util_percent_pmc": ent["mfma_util_percent_pmc"],
+                         "launches_per_step": ent["launches_per_step"],
+                         "algorithmic_gflop_per_launch": ent["algorithmic_gflop_per_launch"],
+                         "avg_launch_ms": ent["avg_launch_ms"], "kernel_ms_per_step": ent["kernel_ms_per_step"],
+                         "share_of_step": ent["kernel_ms_per_step"] / ms_per_step,
+                         "other_mfma_kernels": other,
+                         "all_conv_launches_per_step": n_launch, "all_conv_ms_per_step": conv_ms,
+                         "all_conv_algorithmic_tflops": conv_flops / (conv_ms * 1e-3) / 1e12},
             "whole_step_tflops": conv_flops / (ms_per_step * 1e-3) / 1e12,
         }
         if not args.no_cpu_baseline and world == 1:

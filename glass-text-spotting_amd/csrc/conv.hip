@@ -135,11 +135,14 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     for (int i = 0; i < B_LOADS; ++i)
       breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, b_voff[i], kt * (BK * 4), 0));
     // advance the uniform tap/channel position to the next k-tile
+    // (branch-free, so the k-loop body stays one scheduling region)
     f_c0 += BK;
-    if (f_c0 >= p.Cin) {
-      f_c0 = 0;
-      if (++f_dw == p.KW) { f_dw = 0; ++f_dh; }
-    }
+    const int wrap_c = f_c0 >= p.Cin ? 1 : 0;
+    f_c0 = wrap_c ? 0 : f_c0;
+    f_dw += wrap_c;
+    const int wrap_w = f_dw == p.KW ? 1 : 0;
+    f_dw = wrap_w ? 0 : f_dw;
+    f_dh += wrap_w;
   };
 
   auto load_tile_generic = [&](int kt) {
@@ -199,7 +202,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   __syncthreads();
   for (int kt = 0; kt < p.nk; ++kt) {
     const bool more = kt + 1 < p.nk;
-    if (more) load_tile(kt + 1);
+    // FAST: unconditional (after the last k-tile the bounds-checked loads just return zeros / unused data),
+    // so the whole k-tile is one scheduling region and the loads can be metered out between the MFMAs below
+    if (FAST || more) load_tile(kt + 1);
     const int cur = NSTAGE == 2 ? (kt & 1) : 0;
     const float* a_frag = a_frag0 + cur * STAGE;
     const float* b_frag = b_frag0 + cur * STAGE;
@@ -221,6 +226,17 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
           }
         }
+      }
+    }
+    if constexpr (FAST) {
+      // A burst of vector-memory instructions fills the CU's address queue and the wave then sits on its next
+      // load instead of issuing an MFMA; one load per PER MFMAs keeps the queue shallow (measured on the
+      // Winograd kernel: +10%).
+      constexpr int NL = A_LOADS + B_LOADS, NM = (BK / 8) * 4 * TM * TN, PER = NM / NL;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
       }
     }
     if (NSTAGE == 2) {

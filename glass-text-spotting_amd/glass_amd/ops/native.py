@@ -68,6 +68,11 @@ def conv_out_size(H, W, KH, KW, stride, padding):
 _WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": collections.OrderedDict(), "max": 512}
 
 
+def last_conv_path() -> str:
+    """'winograd' or 'direct': which kernel the most recent conv2d_nhwc call launched (bench/profiling aid)."""
+    return _WINO.get("last_path", "direct")
+
+
 def set_winograd(enabled: bool) -> bool:
     """Route eligible 3x3 convolutions through glass_conv3x3_winograd_nhwc (default on; GLASS_WINOGRAD=0 turns
     it off).  Returns the previous setting."""
@@ -129,6 +134,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     use_wino = _WINO["enabled"] if winograd is None else winograd
     if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
         u = _winograd_weights(w)
+        _WINO["last_path"] = "winograd"
         check(lib().glass_conv3x3_winograd_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
                                                 c_void_p(_dev(bias, "bias") if bias is not None else None),
                                                 c_void_p(_dev(residual, "residual") if residual is not None else None),
@@ -137,6 +143,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         return out
     if winograd:
         raise GlassLibraryError("winograd=True but glass_winograd_supported() rejects this layer")
+    _WINO["last_path"] = "direct"
     check(lib().glass_conv2d_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
                                   c_void_p(_dev(bias, "bias") if bias is not None else None),
                                   c_void_p(_dev(residual, "residual") if residual is not None else None),

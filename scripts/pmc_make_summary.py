@@ -1,0 +1,54 @@
+"""Fold the three rocprofv3 --pmc passes (scripts/pmc_summary.py outputs) into profiles/r01_pmc_conv_summary.json.
+
+    python scripts/pmc_make_summary.py gpurun_out/pmc_FETCH_SIZE.json gpurun_out/pmc_WRITE_SIZE.json \
+        gpurun_out/pmc_MFMA.json > profiles/r01_pmc_conv_summary.json
+
+Per MFMA kernel: HBM bytes per launch = 2 x FETCH_SIZE KB (gfx950 under-reports 16-byte/lane streaming reads by
+2x, MI355X_MICROARCH.md HBM section; checked on this path against maxpool_nhwc_kernel whose traffic is known)
++ WRITE_SIZE KB (exact); MfmaUtil = sum over SIMDs of SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs).
+"""
+import json
+import sys
+
+fetch, write, mfma = (json.load(open(p)) for p in sys.argv[1:4])
+KEYS = {"conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, true>",
+        "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, true>",
+        "conv_igemm_f32_128x64": "conv_igemm_f32<2, 2, 2, 1, 1, 4, 32, true>"}
+
+
+def pick(js, sub, counter):
+    for r in js["per_kernel"]:
+        if sub in r["kernel"] and r["counter"] == counter:
+            return r
+    return None
+
+
+def ndisp(js, sub):
+    for r in js.get("dispatches", []):
+        if sub in r["kernel"]:
+            return r["n"], r["total_ns"]
+    return None, None
+
+
+out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE> --kernel-trace -- "
+                  "python bench.py --steps 1 --warmup 1 --no-cpu-baseline (three separate passes; summarised on the GPU box "
+                  "with scripts/pmc_summary.py, folded with scripts/pmc_make_summary.py)",
+       "calibration": {"kernel": "maxpool_nhwc_kernel", "known_read_MB": 369.1, "FETCH_SIZE_MB_raw": 204.72888,
+                       "known_write_MB": 101.2, "WRITE_SIZE_MB_raw": 101.187584,
+                       "note": "FETCH_SIZE under-reports 16-B/lane streaming reads ~2x on gfx950 (MI355X_MICROARCH.md HBM "
+                               "section; measured once on this path, round 1); WRITE_SIZE is exact"}}
+for key, sub in KEYS.items():
+    f, w = pick(fetch, sub, "FETCH_SIZE"), pick(write, sub, "WRITE_SIZE")
+    b, g = pick(mfma, sub, "SQ_VALU_MFMA_BUSY_CYCLES"), pick(mfma, sub, "GRBM_GUI_ACTIVE")
+    if not (f and w and b and g):
+        continue
+    n, tot_ns = ndisp(mfma, sub)
+    busy_per_launch = b["sum"] / n if n else None
+    ent = {"kernel": f["kernel"], "dispatches_sampled": n,
+           "FETCH_SIZE_KB_per_launch_raw": f["mean_per_dispatch"], "WRITE_SIZE_KB_per_launch_raw": w["mean_per_dispatch"],
+           "hbm_bytes_per_launch_corrected": 1024.0 * (2.0 * f["mean_per_dispatch"] + w["mean_per_dispatch"]),
+           "mfma_busy_cycles_sum_per_launch": busy_per_launch, "grbm_gui_active_mean": g["mean_per_dispatch"],
+           "MfmaUtil_percent": 100.0 * busy_per_launch / (g["mean_per_dispatch"] * 1024.0) if busy_per_launch else None,
+           "avg_launch_us_under_pmc": tot_ns / n / 1e3 if n else None}
+    out[key] = ent
+print(json.dumps(out, indent=1))
