@@ -11,28 +11,38 @@ static inline int grid_for(long n, int block) {
 }
 
 // ---------------------------------------------------------------- max pool (C % 4 == 0)
-__global__ void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4, int KH,
-                                    int KW, int sh, int sw, int ph, int pw, int Ho, int Wo) {
-  const long total = (long)N * Ho * Wo * C4;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % C4);
-    long t = idx / C4;
-    const int wo = (int)(t % Wo);
-    t /= Wo;
-    const int ho = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+// One thread per (output pixel, 4 channels); blockIdx.y = output row (n, ho) so the only integer division left
+// is the 32-bit (wo, c4) split, and the window loops are compile-time for the shapes the path uses (3x3 / 2x2 /
+// 2x1).  The first version (flat 64-bit index, three 64-bit divisions per output) was VALU-bound at 3x the
+// kernel's HBM time.
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float4* __restrict__ x, float4* __restrict__ y, int H, int W,
+                                                           int C4, int kh_rt, int kw_rt, int sh, int sw, int ph, int pw,
+                                                           int Ho, int Wo, int rows) {
+  const int kh_n = KH > 0 ? KH : kh_rt, kw_n = KW > 0 ? KW : kw_rt;
+  const int per_row = Wo * C4;
+  for (int row = blockIdx.y; row < rows; row += gridDim.y) {      // row = n * Ho + ho
+  const int n = row / Ho, ho = row - n * Ho;
+  const int h0 = ho * sh - ph;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per_row; e += gridDim.x * blockDim.x) {
+    const int wo = e / C4, c4 = e - wo * C4;
+    const int w0 = wo * sw - pw;
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    for (int kh = 0; kh < KH; ++kh) {
-      const int hi = ho * sh - ph + kh;
+#pragma unroll
+    for (int kh = 0; kh < kh_n; ++kh) {
+      const int hi = h0 + kh;
       if ((unsigned)hi >= (unsigned)H) continue;
-      for (int kw = 0; kw < KW; ++kw) {
-        const int wi = wo * sw - pw + kw;
+      const float4* xr = x + ((long)(n * H + hi) * W) * C4 + c4;
+#pragma unroll
+      for (int kw = 0; kw < kw_n; ++kw) {
+        const int wi = w0 + kw;
         if ((unsigned)wi >= (unsigned)W) continue;
-        const float4 v = reinterpret_cast<const float4*>(x)[((long)(n * H + hi) * W + wi) * C4 + c4];
+        const float4 v = xr[(long)wi * C4];
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    reinterpret_cast<float4*>(y)[idx] = m;
+    y[(long)row * per_row + e] = m;
+  }
   }
 }
 
@@ -42,9 +52,20 @@ extern "C" int glass_maxpool2d_nhwc(const float* x, float* y, int N, int H, int 
   GLASS_CHECK_ARG(C % 4 == 0 && C > 0, "glass_maxpool2d_nhwc: C=%d must be a multiple of 4", C);
   GLASS_CHECK_ARG(Ho == (H + 2 * ph - KH) / sh + 1 && Wo == (W + 2 * pw - KW) / sw + 1, "glass_maxpool2d_nhwc: bad Ho/Wo");
   if (N == 0) return GLASS_OK;
-  const long total = (long)N * Ho * Wo * (C / 4);
-  hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W,
-                     C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo);
+  const long rows = (long)N * Ho, per_row = (long)Wo * (C / 4);
+  GLASS_CHECK_ARG(rows <= 0x7fffffffL && per_row <= 0x7fffffffL, "glass_maxpool2d_nhwc: tensor too large");
+  const dim3 grid((unsigned)((per_row + 255) / 256 < 64 ? (per_row + 255) / 256 : 64), (unsigned)(rows < 65535 ? rows : 65535));
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  hipStream_t s = (hipStream_t)stream;
+  if (KH == 3 && KW == 3)
+    hipLaunchKernelGGL((maxpool_nhwc_kernel<3, 3>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
+  else if (KH == 2 && KW == 2)
+    hipLaunchKernelGGL((maxpool_nhwc_kernel<2, 2>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
+  else if (KH == 2 && KW == 1)
+    hipLaunchKernelGGL((maxpool_nhwc_kernel<2, 1>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
+  else
+    hipLaunchKernelGGL((maxpool_nhwc_kernel<0, 0>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
   GLASS_CHECK_LAUNCH("glass_maxpool2d_nhwc");
   return GLASS_OK;
 }

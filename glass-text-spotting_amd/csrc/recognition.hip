@@ -312,7 +312,6 @@ extern "C" int glass_bilstm_recurrence(const float* xg, const float* w_hh_packed
 // A persistent workgroup per RoI group has to pull all 2.6 MB of decoder weights through ONE CU per step
 // (80 us/step measured); spreading each step over the chip costs two launch boundaries (~2 us each).
 constexpr int DEC_D = 256;
-constexpr int DEC_RB = 4;
 constexpr int DEC_TMAX = 64;
 constexpr int DEC_CMAX = 256;
 constexpr int GRU_RB = 16;
@@ -329,6 +328,9 @@ struct DecParams {
 };
 
 // step < 0: only the attention part (initial state h = 0, y = 0); do_att == 0: only the fc part (last step)
+// DEC_RB = RoIs per workgroup: 4 when there are enough RoIs to fill the chip with 4-RoI workgroups, else 2 or 1
+// (R = 256: 64 workgroups of 4 leave 3/4 of the CUs idle for 38 us per step; 256 workgroups of 1 take 12 us).
+template <int DEC_RB>
 __global__ __launch_bounds__(256) void dec_fc_att_kernel(DecParams p, const float* __restrict__ hcur, int step, int do_att) {
   __shared__ __attribute__((aligned(16))) float h[DEC_RB][DEC_D];
   __shared__ float sproj[DEC_RB][DEC_D];
@@ -565,12 +567,18 @@ extern "C" int glass_attention_decode(const float* x, const float* xproj, const 
   p.yprev = reinterpret_cast<int*>(ws + (size_t)R * D * 4);
   hipError_t e = hipMemsetAsync(p.h0, 0, (size_t)R * D * sizeof(float), s);      // initial state h = 0
   if (e != hipSuccess) { glass_set_error("glass_attention_decode: memset: %s", hipGetErrorString(e)); return GLASS_EHIP; }
-  const dim3 ga(cdiv(R, DEC_RB)), gg(cdiv(R, GRU_RB), DEC_D / GRU_UB);
+  const int rb = R >= 1024 ? 4 : R >= 512 ? 2 : 1;
+  const dim3 ga(cdiv(R, rb)), gg(cdiv(R, GRU_RB), DEC_D / GRU_UB);
   float* hb[2] = {p.h0, p.h1};
-  hipLaunchKernelGGL(dec_fc_att_kernel, ga, dim3(256), 0, s, p, hb[0], -1, 1);               // attention for step 0
+  auto fc_att = [&](const float* hcur, int step, int do_att) {
+    if (rb == 4) hipLaunchKernelGGL(dec_fc_att_kernel<4>, ga, dim3(256), 0, s, p, hcur, step, do_att);
+    else if (rb == 2) hipLaunchKernelGGL(dec_fc_att_kernel<2>, ga, dim3(256), 0, s, p, hcur, step, do_att);
+    else hipLaunchKernelGGL(dec_fc_att_kernel<1>, ga, dim3(256), 0, s, p, hcur, step, do_att);
+  };
+  fc_att(hb[0], -1, 1);                                                                       // attention for step 0
   for (int step = 0; step < max_len; ++step) {
     hipLaunchKernelGGL(dec_gru_kernel, gg, dim3(256), 0, s, p, hb[step & 1], hb[(step + 1) & 1]);
-    hipLaunchKernelGGL(dec_fc_att_kernel, ga, dim3(256), 0, s, p, hb[(step + 1) & 1], step, step + 1 < max_len ? 1 : 0);
+    fc_att(hb[(step + 1) & 1], step, step + 1 < max_len ? 1 : 0);
   }
   GLASS_CHECK_LAUNCH("glass_attention_decode");
   hipLaunchKernelGGL(decode_break_mask_kernel, dim3(num_images), dim3(256), 0, s, pred_scratch, roi_image, R, max_len, C, eos,
