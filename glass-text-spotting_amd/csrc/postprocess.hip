@@ -141,6 +141,25 @@ __device__ void merge_pair(const float* b1, const float* b2, float s1, float s2,
   out[0] = (float)cx; out[1] = (float)cy; out[2] = (float)width; out[3] = (float)height; out[4] = (float)angle;
 }
 
+// Circumscribed circles disjoint (with slack) -> the rectangles cannot intersect -> IoU is exactly 0; skips the
+// polygon clipping for the (vast majority of) far-apart word pairs.
+__device__ __forceinline__ bool pp_far_apart(const float* a, const float* b) {
+  const float dx = a[0] - b[0], dy = a[1] - b[1];
+  const float r = 0.5f * (sqrtf(a[2] * a[2] + a[3] * a[3]) + sqrtf(b[2] * b[2] + b[3] * b[3]));
+  return dx * dx + dy * dy > r * r * 1.001f + 1e-2f;
+}
+
+// q-th pair (i < j) of the strict upper triangle of an n x n matrix, row-major
+__device__ __forceinline__ void pp_pair(int q, int n, int& i, int& j) {
+  const float b = (float)(2 * n - 1);
+  int r = (int)((b - sqrtf(fmaxf(b * b - 8.f * (float)q, 0.f))) * 0.5f);
+  r = max(0, min(r, n - 2));
+  while (r + 1 <= n - 2 && (r + 1) * (2 * n - (r + 1) - 1) / 2 <= q) ++r;
+  while (r > 0 && r * (2 * n - r - 1) / 2 > q) --r;
+  i = r;
+  j = q - r * (2 * n - r - 1) / 2 + r + 1;
+}
+
 __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams p) {
   __shared__ float bx[PP_KMAX][5], snap[PP_KMAX][5], tmpb[PP_KMAX][5];
   __shared__ float sc[PP_KMAX], tmps[PP_KMAX];
@@ -187,10 +206,12 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
     if (tid == 0) s_any = 0;
     __syncthreads();
     // IoA matrix (upper triangle), same algebra as pairwise_ioa_rotated (glass/structures/boxes.py:33-48)
-    for (int pr = tid; pr < n * n; pr += PP_THREADS) {
-      const int i = pr / n, j = pr - i * n;
+    const int npair = n * (n - 1) / 2;
+    for (int q = tid; q < npair; q += PP_THREADS) {
+      int i, j;
+      pp_pair(q, n, i, j);
       float v = 0.f;
-      if (i < j) {
+      if (!pp_far_apart(snap[i], snap[j])) {
         const float iou = rotated_iou(make_rbox(snap[i][0], snap[i][1], snap[i][2], snap[i][3], snap[i][4]),
                                       make_rbox(snap[j][0], snap[j][1], snap[j][2], snap[j][3], snap[j][4]));
         const float a1 = snap[i][2] * snap[i][3], a2 = snap[j][2] * snap[j][3];
@@ -201,23 +222,22 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
     }
     __syncthreads();
     // valid pair mask -> ioa[j][i] (lower triangle reused as flag storage: 1.0 = valid)
-    for (int pr = tid; pr < n * n; pr += PP_THREADS) {
-      const int i = pr / n, j = pr - i * n;
-      if (i < j) {
-        bool ok = false;
-        const float v = ioa[i][j];
-        if (v >= p.minimal_ioa) {
-          float ad = snap[j][4] - snap[i][4];
-          ad = fabsf(floor_mod_pp(ad + 180.f, 360.f) - 180.f);
-          const bool sim_angle = (ad < p.max_angle_diff) || (ad > (180.f - p.max_angle_diff));
-          const float hr = snap[j][3] / snap[i][3];
-          const bool sim_h = (p.height_ratio < hr) && (hr < (1.f / (p.height_ratio + 1e-6f)));
-          const bool vs = fminf(sc[i], sc[j]) >= p.valid_score;
-          ok = sim_angle && sim_h && vs && (v >= p.merge_ioa);
-        }
-        ioa[j][i] = ok ? 1.f : 0.f;
-        if (ok) s_any = 1;
+    for (int q = tid; q < npair; q += PP_THREADS) {
+      int i, j;
+      pp_pair(q, n, i, j);
+      bool ok = false;
+      const float v = ioa[i][j];
+      if (v >= p.minimal_ioa) {
+        float ad = snap[j][4] - snap[i][4];
+        ad = fabsf(floor_mod_pp(ad + 180.f, 360.f) - 180.f);
+        const bool sim_angle = (ad < p.max_angle_diff) || (ad > (180.f - p.max_angle_diff));
+        const float hr = snap[j][3] / snap[i][3];
+        const bool sim_h = (p.height_ratio < hr) && (hr < (1.f / (p.height_ratio + 1e-6f)));
+        const bool vs = fminf(sc[i], sc[j]) >= p.valid_score;
+        ok = sim_angle && sim_h && vs && (v >= p.merge_ioa);
       }
+      ioa[j][i] = ok ? 1.f : 0.f;
+      if (ok) s_any = 1;
     }
     __syncthreads();
     if (!s_any) break;
@@ -234,43 +254,60 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
     }
     __syncthreads();
     // nms_rotated(0.99): IoU matrix, stable descending-score order, greedy suppression, reorder survivors
-    for (int pr = tid; pr < n * n; pr += PP_THREADS) {
-      const int i = pr / n, j = pr - i * n;
-      if (i < j) {
-        const float iou = rotated_iou(make_rbox(bx[i][0], bx[i][1], bx[i][2], bx[i][3], bx[i][4]),
-                                      make_rbox(bx[j][0], bx[j][1], bx[j][2], bx[j][3], bx[j][4]));
-        ioa[i][j] = iou;
-        ioa[j][i] = iou;
-      }
+    for (int q = tid; q < npair; q += PP_THREADS) {
+      int i, j;
+      pp_pair(q, n, i, j);
+      float iou = 0.f;
+      if (!pp_far_apart(bx[i], bx[j]))
+        iou = rotated_iou(make_rbox(bx[i][0], bx[i][1], bx[i][2], bx[i][3], bx[i][4]),
+                          make_rbox(bx[j][0], bx[j][1], bx[j][2], bx[j][3], bx[j][4]));
+      ioa[i][j] = iou;
+      ioa[j][i] = iou;
+    }
+    // stable descending order by rank counting (ties keep the lower index first, as the host's stable sort)
+    for (int i = tid; i < n; i += PP_THREADS) {
+      const float si = sc[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (sc[j] > si || (sc[j] == si && j < i)) ? 1 : 0;
+      order[rank] = i;
     }
     __syncthreads();
-    if (tid == 0) {
-      for (int i = 0; i < n; ++i) { order[i] = i; flag[i] = 0; }
-      for (int i = 1; i < n; ++i) {                    // stable insertion sort, descending score
-        const int key = order[i];
-        int j = i - 1;
-        while (j >= 0 && sc[order[j]] < sc[key]) { order[j + 1] = order[j]; --j; }
-        order[j + 1] = key;
-      }
-      int m = 0;
+    // greedy suppression by ONE wavefront (no barriers): lane l owns sorted positions l and l + 64
+    if (tid < 64) {
+      const int c0 = tid, c1 = tid + 64;
+      const int o0 = c0 < n ? order[c0] : 0, o1 = c1 < n ? order[c1] : 0;
+      int rem0 = c0 < n ? 0 : 1, rem1 = c1 < n ? 0 : 1;
       for (int a = 0; a < n; ++a) {
+        const int ra = a < 64 ? __shfl(rem0, a) : __shfl(rem1, a - 64);
+        if (ra) continue;                                    // wave-uniform
         const int i = order[a];
-        if (flag[i]) continue;
-        for (int e = 0; e < 5; ++e) tmpb[m][e] = bx[i][e];
-        tmps[m] = sc[i];
-        tmpi[m] = src[i];
-        ++m;
-        for (int c = a + 1; c < n; ++c) {
-          const int j = order[c];
-          if (!flag[j] && ioa[i][j] >= 0.99f) flag[j] = 1;
-        }
+        if (c0 > a && !rem0 && ioa[i][o0] >= 0.99f) rem0 = 1;
+        if (c1 > a && c1 < n && !rem1 && ioa[i][o1] >= 0.99f) rem1 = 1;
       }
-      for (int i = 0; i < m; ++i) {
+      // ordered compaction of the survivors (sorted order)
+      const unsigned long long k0 = __ballot(c0 < n && !rem0), k1 = __ballot(c1 < n && !rem1);
+      const unsigned long long below = tid == 0 ? 0ull : (~0ull >> (64 - tid));
+      const int d0 = __popcll(k0 & below), d1 = __popcll(k0) + __popcll(k1 & below);
+      if (c0 < n && !rem0) {
+        for (int e = 0; e < 5; ++e) tmpb[d0][e] = bx[o0][e];
+        tmps[d0] = sc[o0];
+        tmpi[d0] = src[o0];
+      }
+      if (c1 < n && !rem1) {
+        for (int e = 0; e < 5; ++e) tmpb[d1][e] = bx[o1][e];
+        tmps[d1] = sc[o1];
+        tmpi[d1] = src[o1];
+      }
+      if (tid == 0) s_n = __popcll(k0) + __popcll(k1);
+    }
+    __syncthreads();
+    {
+      const int m = s_n;
+      for (int i = tid; i < m; i += PP_THREADS) {
         for (int e = 0; e < 5; ++e) bx[i][e] = tmpb[i][e];
         sc[i] = tmps[i];
         src[i] = tmpi[i];
       }
-      s_n = m;
     }
     __syncthreads();
   }
@@ -281,17 +318,27 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
   float* prb = &ioa[0][0] + PP_KMAX * 32;                         // [n][T], T <= 32
   const int n_fin = s_n;
   if (p.do_text) {
-    for (int pr = tid; pr < n_fin * p.T; pr += PP_THREADS) {
+    // wavefront per (box, step) row: coalesced reads, shuffle arg-max (first maximum wins, as torch.max)
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int pr = wave; pr < n_fin * p.T; pr += PP_THREADS / 64) {
       const int i = pr / p.T, t = pr - i * p.T;
       const float* row = p.text + (((long)n_img * p.K + src[i]) * p.T + t) * (long)p.C;
-      float best = row[0];
-      int bi = 0;
-      for (int c = 1; c < p.C; ++c) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int c = lane; c < p.C; c += 64) {
         const float v = row[c];
-        if (v > best) { best = v; bi = c; }
+        if (v > best || bi == 0x7fffffff) { best = v; bi = c; }
       }
-      chr[i * p.T + t] = bi;
-      prb[i * p.T + t] = best;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+      }
+      if (lane == 0) {
+        chr[i * p.T + t] = bi;
+        prb[i * p.T + t] = best;
+      }
     }
   }
   __syncthreads();
