@@ -264,8 +264,34 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     constexpr int VPR = CW / 4;                    // float4 per staged row
     constexpr int ITERS = BM * VPR / 256;
     float* stage = smem;
+    // Residual prefetch: a chunk's residual float4s are requested together before its LDS transposition
+    // (address-selected, so the loads are unconditional and all in flight) instead of one dependent HBM round
+    // trip per output row inside the store loop.
+    float4 rres[ITERS];
+    auto prefetch_res = [&](int c) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + 256 * it;
+        const int row = idx / VPR, c4 = idx - row * VPR;
+        const int m = m0 + row;
+        const int co = n0 + c * CW + c4 * 4;
+        const bool ok = m < p.M && co < p.Cout;
+        long roff;
+        if (p.res_mode == 1) {
+          roff = (long)m * p.ldr + co;
+        } else {
+          const int n = m / HoWo;
+          const int rem = m - n * HoWo;
+          const int ho = rem / p.Wo;
+          const int wo = rem - ho * p.Wo;
+          roff = ((long)n * HoWo2 + (long)(ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * p.ldr + co;
+        }
+        rres[it] = *reinterpret_cast<const float4*>(p.res + (ok ? roff : 0));
+      }
+    };
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
+      if (p.res_mode != 0) prefetch_res(c);        // in flight across the LDS transposition below
       __syncthreads();                             // operand reads / previous chunk's read-back done
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -295,17 +321,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
           }
           if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           if (p.res_mode != 0) {
-            long roff;
-            if (p.res_mode == 1) {
-              roff = (long)m * p.ldr + co;
-            } else {
-              const int n = m / HoWo;
-              const int rem = m - n * HoWo;
-              const int ho = rem / p.Wo;
-              const int wo = rem - ho * p.Wo;
-              roff = ((long)n * HoWo2 + (long)(ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * p.ldr + co;
-            }
-            const float4 r = *reinterpret_cast<const float4*>(p.res + roff);
+            const float4 r = rres[it];
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
           }
           if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -402,8 +418,19 @@ extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const
                ((uintptr_t)y & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
                (d->res_mode == 0 || (d->ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0))) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
+  static const int force_cfg = getenv("GLASS_CONV_CFG") ? atoi(getenv("GLASS_CONV_CFG")) : 0;   // tuning aid
+  if (force_cfg == 1) return launch_conv_impl<2, 2, 2, 2, 1, 3, 32>(p, s);
+  if (force_cfg == 2) return launch_conv_impl<1, 4, 2, 1, 1, 4, 32>(p, s);
+  if (force_cfg == 3) return launch_conv_impl<2, 2, 2, 1, 1, 4, 32>(p, s);
+  if (force_cfg == 4) return launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);   // 64 x 64, 8 blocks/CU
+  if (force_cfg == 5) return launch_conv_impl<1, 4, 1, 1, 1, 6, 32>(p, s);   // 32 x 128
   if (d->Cout <= 32) return launch_conv_impl<4, 1, 1, 1, 1, 4, 32>(p, s);   // 128 x 32
   if (d->Cout <= 64) return launch_conv_impl<2, 2, 2, 1, 1, 4, 32>(p, s);   // 128 x 64
+  // short K (1x1 convs with Cin <= 256; most carry a fused residual): few k-tiles per block, so the block is mostly
+  // prologue + epilogue and the layer is HBM-bound - 64x64 tiles at 8 blocks/CU hide those latencies far better
+  // than 3 big blocks (64->256 +residual: 3.1 -> 4.7 TB/s; 128->512: 2.3 -> 3.1; 256->1024: 88 -> 108 TFLOP/s)
+  static const int k64 = getenv("GLASS_CONV_K64") ? atoi(getenv("GLASS_CONV_K64")) : 256;       // tuning aid
+  if (p.Ktot <= k64) return launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);   // 64 x 64
   // few 128x128 tiles (deep small maps, linear layers on <=800 rows): halve the tile height so the
   // grid covers the 256 CUs at least ~2x
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(d->Cout, 128);

@@ -215,6 +215,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
   // Y = At M A with At = [[1,1,1,0],[0,1,-1,-1]].  This wave holds row i = wv of M (its four xi are the
   // columns j): fold the columns first, Z[i][b] = sum_j M[i][j] At[b][j], then meet the other rows in LDS.
   // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+  // Output role: thread = (4-channel chunk c4, tile ts + 16*pass).  The residual float4s of all 16 output pixels
+  // of this thread are requested here, before the LDS exchange, address-selected so that the loads are
+  // unconditional and all in flight together (one HBM round trip per block instead of four in series).
+  const int c4 = tid & 15, ts = tid >> 4;
+  const int co = n0 + c4 * 4;
+  long m_base[4];                                 // pixel index of the tile's top-left output, -1: no such tile
+  int oh_ok[4], ow_ok[4];                         // bit a / bit b set: row 2*th+a / column 2*tw+b exists
+  float4 rres[16];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int t = t0 + pass * 16 + ts;
+    const bool tv = t < p.ntiles;
+    const int n = t / tpi;
+    const int rem = t - n * tpi;
+    const int th = rem / p.TW;
+    const int tw = rem - th * p.TW;
+    m_base[pass] = tv ? ((long)n * p.H + 2 * th) * p.W + 2 * tw : -1;
+    oh_ok[pass] = tv ? (1 | ((2 * th + 1 < p.H) ? 2 : 0)) : 0;
+    ow_ok[pass] = tv ? (1 | ((2 * tw + 1 < p.W) ? 2 : 0)) : 0;
+    if (p.res_mode == 1) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const bool ok = ((oh_ok[pass] >> a) & 1) && ((ow_ok[pass] >> b) & 1);
+          const long m = m_base[pass] + (long)a * p.W + b;
+          rres[pass * 4 + b * 2 + a] = *reinterpret_cast<const float4*>(p.res + (ok ? m * p.ldr + co : 0));
+        }
+    }
+  }
   float* zs = smem;
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
@@ -229,39 +259,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
         zs[((wv * 2 + 1) * WT + row) * ZLD + col] = m1 - m2 - m3;
       }
   __syncthreads();
-  const int c4 = tid & 15, ts = tid >> 4;
-  const int co = n0 + c4 * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + co);
-#pragma unroll 1
+#pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int tile = pass * 16 + ts;
-    const int t = t0 + tile;
-    if (t >= p.ntiles) continue;
-    const int n = t / tpi;
-    const int rem = t - n * tpi;
-    const int th = rem / p.TW;
-    const int tw = rem - th * p.TW;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int wo = 2 * tw + b;
-      if (wo >= p.W) continue;
+      if (!((ow_ok[pass] >> b) & 1)) continue;
       const float4 z0 = *reinterpret_cast<const float4*>(&zs[((0 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
       const float4 z1 = *reinterpret_cast<const float4*>(&zs[((1 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
       const float4 z2 = *reinterpret_cast<const float4*>(&zs[((2 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
       const float4 z3 = *reinterpret_cast<const float4*>(&zs[((3 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const int ho = 2 * th + a;
-        if (ho >= p.H) continue;
+        if (!((oh_ok[pass] >> a) & 1)) continue;
         float4 v = a == 0 ? add4(add4(z0, z1), z2) : sub4(sub4(z1, z2), z3);
         v = add4(v, bv);
         if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        const long m = ((long)n * p.H + ho) * p.W + wo;
-        if (p.res_mode == 1) {
-          const float4 r = *reinterpret_cast<const float4*>(p.res + m * p.ldr + co);
-          v = add4(v, r);
-        }
+        const long m = m_base[pass] + (long)a * p.W + b;
+        if (p.res_mode == 1) v = add4(v, rres[pass * 4 + b * 2 + a]);
         if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4*>(p.y + m * p.ldy + p.ycoff + co) = v;
       }

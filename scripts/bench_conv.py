@@ -27,6 +27,9 @@ LAYERS = [
     ("fusion out 3x3 512->256 R=256", 256, 8, 32, 512, 256, 3, 1, 1),
     ("fc1 800x12544->2048", 800, 1, 1, 12544, 2048, 1, 1, 0),
     ("rpn p6 3x3 256 @16", 8, 16, 16, 256, 256, 3, 1, 1),
+    ("res3.conv1 1x1 512->128", 8, 128, 128, 512, 128, 1, 1, 0),
+    ("res4.conv1 1x1 1024->256", 8, 64, 64, 1024, 256, 1, 1, 0),
+    ("res5.conv3 1x1 512->2048", 8, 32, 32, 512, 2048, 1, 1, 0),
 ]
 def timed(fn, it=5):
     fn()
