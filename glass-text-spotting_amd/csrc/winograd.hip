@@ -53,10 +53,19 @@ struct WinoParams {
   int ldx, ldy, ycoff, ldr, relu, res_mode;
   int tiles_m, tiles_n;
   unsigned x_bytes, u_bytes;
+  unsigned magic_tpi, magic_tw;    // floor(2^32 / d) for the two tile-index divisions (fast_div)
 };
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+// t / d for 0 <= t < 2^31 with magic = floor(2^32 / d): the mul-high estimate is low by at most one (6 instructions
+// instead of the ~40 of a 32-bit integer division; the epilogue alone did eight of those per thread = 1.5 us).
+__device__ __forceinline__ int fast_div(int t, int d, unsigned magic) {
+  int q = d == 1 ? t : (int)__umulhi((unsigned)t, magic);
+  if (t - q * d >= d) ++q;
+  return q;
+}
+
 __device__ __forceinline__ float comp(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
@@ -84,9 +93,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
   {
     const int t = t0 + tl;
     const bool tv = t < p.ntiles;
-    const int n = t / tpi;
+    const int n = fast_div(t, tpi, p.magic_tpi);
     const int rem = t - n * tpi;
-    const int th = rem / p.TW;
+    const int th = fast_div(rem, p.TW, p.magic_tw);
     const int tw = rem - th * p.TW;
     const int h0 = 2 * th - 1, w0 = 2 * tw - 1;
 #pragma unroll
@@ -99,12 +108,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
       }
   }
   float4 d[16], t[16];
-  auto load_patch1 = [&](int kt, int i) {
-    d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[i], kt * (WK * 4), 0));
+  auto load_patch1 = [&](int kt, int i, __amdgpu_buffer_rsrc_t rs) {
+    d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], kt * (WK * 4), 0));
   };
   auto load_patch = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) load_patch1(kt, i);
+    for (int i = 0; i < 16; ++i) load_patch1(kt, i, xr);
   };
   // V[stage][xi][tile][16]: a row is 64 bytes, so four consecutive rows span the 64 banks once; XOR-ing the
   // 16-byte slot with (tile/4)%4 spreads the 16 rows a ds_read_b128 service group touches over all 16 slots.
@@ -147,11 +156,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
   const unsigned b_voff = (unsigned)lane * 16u;
   float4 bq[2][4][2];
   // packed U: [tile_n][kt][xi][nb][g] chunks of 1 KiB (64 lanes x float4)
-  auto load_b1 = [&](float4 (&dst)[4][2], int kt, int g, int idx) {
+  auto load_b1r = [&](float4 (&dst)[4][2], int kt, int g, int idx, __amdgpu_buffer_rsrc_t rs) {
     const int base = ((((tile_n * p.nk + kt) * 16 + 4 * wv) * 2) * 2 + g) * 1024;
     const int j = idx >> 1, nb = idx & 1;
-    dst[j][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, base + (j * 4 + nb * 2) * 1024, 0));
+    dst[j][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, b_voff, base + (j * 4 + nb * 2) * 1024, 0));
   };
+  auto load_b1 = [&](float4 (&dst)[4][2], int kt, int g, int idx) { load_b1r(dst, kt, g, idx, ur); };
   auto load_b = [&](float4 (&dst)[4][2], int kt, int g) {
 #pragma unroll
     for (int idx = 0; idx < 8; ++idx) load_b1(dst, kt, g, idx);
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
           } else if (m < 60) {
             const int q = (m - 28) >> 1;
             if (((m - 28) & 1) == 0) col_piece(cur ^ 1, q >> 2, q & 3);
-            else load_patch1(ktnn, q);            // d is free again: patch of k-tile kt+2, a whole g ahead of its use
+            else load_patch1(ktnn, q, xr);        // d is free again: patch of k-tile kt+2, a whole g ahead of its use
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -220,6 +230,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
   // unconditional and all in flight together (one HBM round trip per block instead of four in series).
   const int c4 = tid & 15, ts = tid >> 4;
   const int co = n0 + c4 * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);    // requested now, used after the exchange
+  if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + co);
   long m_base[4];                                 // pixel index of the tile's top-left output, -1: no such tile
   int oh_ok[4], ow_ok[4];                         // bit a / bit b set: row 2*th+a / column 2*tw+b exists
   float4 rres[16];
@@ -227,9 +239,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
   for (int pass = 0; pass < 4; ++pass) {
     const int t = t0 + pass * 16 + ts;
     const bool tv = t < p.ntiles;
-    const int n = t / tpi;
+    const int n = fast_div(t, tpi, p.magic_tpi);
     const int rem = t - n * tpi;
-    const int th = rem / p.TW;
+    const int th = fast_div(rem, p.TW, p.magic_tw);
     const int tw = rem - th * p.TW;
     m_base[pass] = tv ? ((long)n * p.H + 2 * th) * p.W + 2 * tw : -1;
     oh_ok[pass] = tv ? (1 | ((2 * th + 1 < p.H) ? 2 : 0)) : 0;
@@ -259,8 +271,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
         zs[((wv * 2 + 1) * WT + row) * ZLD + col] = m1 - m2 - m3;
       }
   __syncthreads();
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + co);
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int tile = pass * 16 + ts;
@@ -361,6 +371,8 @@ extern "C" int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float
   p.tiles_m = cdiv(p.ntiles, WT);
   p.tiles_n = d->Cout / WN;
   p.x_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldx * 4);
+  p.magic_tpi = (unsigned)(0x100000000ULL / (unsigned long long)(p.TH * p.TW));
+  p.magic_tw = (unsigned)(0x100000000ULL / (unsigned long long)p.TW);
   p.u_bytes = (unsigned)(16L * d->Cout * d->Cin * 4);
   const long nblk = (long)p.tiles_m * p.tiles_n;
   GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv3x3_winograd_nhwc: bad grid");
