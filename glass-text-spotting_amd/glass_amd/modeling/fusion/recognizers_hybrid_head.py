@@ -3,8 +3,9 @@
 Mirrors reference glass/modeling/fusion/recognizers_hybrid_head.py: constructor wiring
 (`_init_box_head` :183-216, `_init_recognizer_head` :445-511), `forward` eval branch
 (:176-181), `_forward_box` (:291-339), `_forward_recognizer` (:513-569) and
-`forward_with_given_boxes` (:571-609; 3-argument form).  The mask branch is off at inference in
-every shipped config (`MASK_INFERENCE: false`) and is not built.
+`forward_with_given_boxes` (:571-609; 3-argument form).  The rotated mask branch (`_forward_mask`, :378-442) is
+off at inference in every shipped config (`MASK_INFERENCE: false`) and runs when the eval CLI's
+`MODEL.ROI_MASK_HEAD.MASK_INFERENCE True` is set.
 
 Two surfaces:
   * the reference's: `forward(images, features, proposals, targets=None) -> (list[Instances], {})`
@@ -41,6 +42,7 @@ class BatchedDetections:
         self.boxes, self.scores, self.orient = boxes, scores, orient
         self.counts_dev, self.counts_host, self.image_sizes = counts_dev, list(counts_host), list(image_sizes)
         self.text = None
+        self.masks = None             # [sum counts, 1, M, M] mask probabilities (MASK_INFERENCE), or padded [N,K,M,M]
         self.roi_start_host = [0]
         for c in self.counts_host[:-1]:
             self.roi_start_host.append(self.roi_start_host[-1] + c)
@@ -64,6 +66,10 @@ class BatchedDetections:
                 else:
                     s0 = self.roi_start_host[n]
                     r.pred_text_prob = self.text[s0:s0 + c]
+            if self.masks is not None:                        # forward_with_given_boxes, :595-606
+                s0 = self.roi_start_host[n]
+                r.pred_masks = self.masks[s0:s0 + c]
+                r.pred_rboxes = r.pred_boxes
             out.append(r)
         return out
 
@@ -111,9 +117,16 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         self.hybrid_net = build_hybrid_feature_extractor(cfg, shape)
         self.fusion_net = build_hybrid_feature_fusion(cfg, shape)
         self.recognizer_head = build_recognizer_head(cfg, shape)
+        # ---- mask branch (:342-376): pooler over ROI_HEADS.IN_FEATURES, built only when it will run
         self.mask_inference = bool(cfg.MODEL.ROI_MASK_HEAD.MASK_INFERENCE)
+        self.mask_head = None
         if self.mask_inference:
-            raise NotImplementedError("rotated mask branch at inference is not built (SURVEY.md §8 f2)")
+            assert cfg.MODEL.MASK_ON, "MASK_INFERENCE needs MODEL.MASK_ON (the checkpoint must carry roi_heads.mask_head.*)"
+            from ..roi_heads.rotated_mask_head import build_mask_head
+            self.mask_pooler_resolution = cfg.MODEL.ROI_MASK_HEAD.POOLER_RESOLUTION
+            self.mask_sampling_ratio = cfg.MODEL.ROI_MASK_HEAD.POOLER_SAMPLING_RATIO
+            mr = self.mask_pooler_resolution
+            self.mask_head = build_mask_head(cfg, ShapeSpec(channels=in_channels, height=mr, width=mr))
         self.local_ch = cfg.MODEL.LOCAL_FEATURE_EXTRACTOR.NUM_FEATURES
         self.two_stream_local = os.environ.get("GLASS_SINGLE_STREAM", "0") != "1"
         self._streams = None
@@ -125,6 +138,8 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         self.hybrid_net.import_weights(sd, device, prefix + "hybrid_net.")
         self.fusion_net.import_weights(sd, device, prefix + "fusion_net.")
         self.recognizer_head.import_weights(sd, device, prefix + "recognizer_head.")
+        if self.mask_head is not None:
+            self.mask_head.import_weights(sd, device, prefix + "mask_head.")
 
     # ================================================================== device-resident path
     def box_branch_batched(self, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor, prop_counts: torch.Tensor,
@@ -161,6 +176,14 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
             inter["fused"] = fused
             return probs, inter
         return probs
+
+    def mask_branch_batched(self, feats: Dict[str, torch.Tensor], boxes: torch.Tensor, roi_image: torch.Tensor) -> torch.Tensor:
+        """`_forward_mask` at inference (:378-442) for all RoIs of the step: ROIAlignRotated 14x14 over
+        ROI_HEADS.IN_FEATURES on the rotated boxes, mask head, sigmoid -> pred_masks [R,1,28,28]."""
+        fl = [feats[f] for f in self.box_in_features]
+        r = self.mask_pooler_resolution
+        pooled = K.roi_align_rotated(fl, self.box_pooler_scales, boxes, roi_image, (r, r), self.mask_sampling_ratio)
+        return self.mask_head.forward_nhwc(pooled)
 
     def _local_extractor_streams(self, crops: torch.Tensor, xcat: torch.Tensor) -> None:
         """Local extractor on all RoIs.  RoIs are independent, so the batch is split in two halves enqueued on
@@ -225,21 +248,32 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         boxes = torch.cat([det.boxes[n, :c] for n, c in enumerate(counts)], 0).contiguous()
         roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
         det.text = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts))
+        if self.mask_inference:
+            det.masks = self.mask_branch_batched(feats, boxes, roi_image)
         return det
 
     def _recognize_into(self, img_nhwc4, feats, results: List[Instances]) -> List[Instances]:
-        if not self.recognizer_on:
-            return results
         counts = [len(r) for r in results]
         R = sum(counts)
-        if R == 0:
-            return results        # reference: recognizer_head returns the instances untouched (recognizer_head_v2.py:151)
         device = img_nhwc4.device
-        boxes = torch.cat([r.pred_boxes.tensor for r in results], 0).contiguous()
-        roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
-        probs = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts))
-        for p, r in zip(probs.split(counts, dim=0), results):
-            r.pred_text_prob = p
+        boxes = roi_image = None
+        if R > 0:
+            boxes = torch.cat([r.pred_boxes.tensor for r in results], 0).contiguous()
+            roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
+        # reference: with no boxes the recognizer head returns the instances untouched (recognizer_head_v2.py:151)
+        if self.recognizer_on and R > 0:
+            probs = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts))
+            for p, r in zip(probs.split(counts, dim=0), results):
+                r.pred_text_prob = p
+        if self.mask_inference:            # forward_with_given_boxes, :594-606
+            if R > 0:
+                masks = self.mask_branch_batched(feats, boxes, roi_image).split(counts, dim=0)
+            else:
+                m = 2 * self.mask_pooler_resolution
+                masks = [torch.zeros((0, 1, m, m), dtype=torch.float32, device=device) for _ in results]
+            for mk, r in zip(masks, results):
+                r.pred_masks = mk
+                r.pred_rboxes = r.pred_boxes
         return results
 
     # ================================================================== reference surface

@@ -22,7 +22,7 @@ from ...checkpoint import load_checkpoint_file
 from ...ops import native as K
 from ...postprocess import build_post_processor
 from ...postprocess.post_processor_academic import detector_postprocess
-from ...structures.core import ImageList, Instances
+from ...structures.core import RotatedBoxes, ImageList, Instances
 from ...utils.registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY
 from ..backbone import resnet_fpn as _resnet_fpn  # noqa: F401  (registers the backbone builder)
 from ..backbone.resnet_fpn import as_nchw_view
@@ -126,14 +126,31 @@ class GeneralizedRCNN(InferenceModule):
         dev = self._device
         scale_xy = torch.tensor(sxy, dtype=torch.float32).to(dev)
         out_hw = torch.tensor(ohw, dtype=torch.int32).to(dev)
-        roi_start = torch.tensor(det.roi_start_host, dtype=torch.int32).to(dev) if det.text is not None else None
+        roi_start = torch.tensor(det.roi_start_host, dtype=torch.int32).to(dev) if (det.text is not None or det.masks is not None) else None
         ob, os_, oo, ot, oc = K.detections_finalize(det.boxes, det.scores, det.orient, det.text, det.counts_dev, roi_start,
                                                     scale_xy, out_hw, float(self._min_box_dim), self._filter_small)
+        om = None
+        if det.masks is not None:
+            # the same ordered compaction for the mask rows (the kernel's "text" slot carries any per-RoI payload)
+            _, _, _, om, _ = K.detections_finalize(det.boxes, det.scores, None, det.masks[:, 0].contiguous(), det.counts_dev,
+                                                   roi_start, scale_xy, out_hw, float(self._min_box_dim), self._filter_small)
         counts = oc.cpu().tolist()
         post = BatchedDetections(ob, os_, oo, oc, counts, out_sizes)
         post.text = ot
         self.last_batch = post
-        return [{"instances": r} for r in post.to_instances()]
+        results = post.to_instances()
+        if om is not None:
+            # detector_postprocess (post_processor_academic.py:167-176): paste on the scaled boxes; pred_rboxes is
+            # scaled once more unless filter_small_boxes' indexing broke its alias with pred_boxes
+            for n, r in enumerate(results):
+                c = counts[n]
+                r.pred_masks = K.paste_rotated_masks(om[n, :c].contiguous(), ob[n, :c].contiguous(), out_sizes[n], 0.5)
+                rb = RotatedBoxes(ob[n, :c].clone())
+                if not self._filter_small:
+                    rb.scale(sxy[n][0], sxy[n][1])
+                    rb.clip(out_sizes[n])
+                r.pred_rboxes = rb
+        return [{"instances": r} for r in results]
 
     def _postprocess(self, instances, batched_inputs, image_sizes):
         out = []

@@ -173,6 +173,38 @@ def maxpool2d_nhwc(x: torch.Tensor, kernel, stride, padding=0) -> torch.Tensor:
     return y
 
 
+def pixel_shuffle2x_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """x [N,H,W,4C] (channel = (a*2+b)*C + c) -> [N,2H,2W,C]: the scatter half of ConvTranspose2d(k=2, s=2)."""
+    _f32c(x, "x")
+    N, H, W, C4 = x.shape
+    C = C4 // 4
+    y = torch.empty((N, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
+    check(lib().glass_pixel_shuffle2x_nhwc(c_void_p(_dev(x)), c_void_p(_dev(y)), N, H, W, C, c_void_p(stream_handle())),
+          "glass_pixel_shuffle2x_nhwc")
+    return y
+
+
+def sigmoid_(x: torch.Tensor) -> torch.Tensor:
+    _f32c(x, "x")
+    check(lib().glass_sigmoid_inplace(c_void_p(_dev(x)), ctypes.c_int64(x.numel()), c_void_p(stream_handle())),
+          "glass_sigmoid_inplace")
+    return x
+
+
+def paste_rotated_masks(masks: torch.Tensor, boxes: torch.Tensor, image_hw: Tuple[int, int], threshold: float = 0.5) -> torch.Tensor:
+    """masks [R,M,M] float, boxes [R,5] -> bool [R,H,W] (threshold >= 0) or uint8 [R,H,W] (threshold < 0)."""
+    _f32c(masks, "masks"); _f32c(boxes, "boxes")
+    R, M, M2 = masks.shape
+    if M != M2:
+        raise GlassLibraryError("Only square mask predictions are supported")
+    H, W = int(image_hw[0]), int(image_hw[1])
+    out = torch.empty((R, H, W), dtype=torch.uint8, device=masks.device)
+    if R:
+        check(lib().glass_paste_rotated_masks(c_void_p(_dev(masks)), c_void_p(_dev(boxes)), R, M, H, W, c_float(threshold),
+                                              c_void_p(_dev(out)), c_void_p(stream_handle())), "glass_paste_rotated_masks")
+    return out.view(torch.bool) if threshold >= 0 else out
+
+
 def preprocess_image(chw: torch.Tensor, mean: Sequence[float], std: Sequence[float], batch: torch.Tensor, n: int) -> None:
     """(chw - mean)/std -> slot n of the zero-padded NHWC4 batch [N,Hp,Wp,4]."""
     _f32c(chw, "image"); _f32c(batch, "batch")

@@ -72,4 +72,15 @@ def detector_postprocess(results: Instances, output_height, output_width, mask_t
         return results
     output_boxes.scale(scale_x, scale_y)
     output_boxes.clip(results.image_size)
-    return results[output_boxes.nonempty()]
+    results = results[output_boxes.nonempty()]
+    if results.has("pred_masks"):          # reference :167-173: paste_masks_in_image on the scaled rotated boxes
+        from ..ops import native as K
+        results.pred_masks = K.paste_rotated_masks(results.pred_masks[:, 0, :, :].contiguous(),
+                                                   results.pred_boxes.tensor.contiguous(), results.image_size,
+                                                   threshold=mask_threshold)
+    if results.has("pred_rboxes"):         # reference :174-176.  forward_with_given_boxes aliases pred_rboxes to
+        # pred_boxes (recognizers_hybrid_head.py:599): unless an indexing step in between (filter_small_boxes) broke
+        # the alias, the in-place scale above already went through pred_rboxes and this one scales it a second time.
+        results.pred_rboxes.scale(scale_x, scale_y)
+        results.pred_rboxes.clip(results.image_size)
+    return results

@@ -168,8 +168,25 @@ class PostProcessorRotatedBoxes:
             o = torch.zeros((1, K_, 2), dtype=torch.float32, device=dev)
             o[0, :n] = preds.orientations
             extra["orientations"] = o
+        # every other per-instance field rides along and is gathered with the survivors, as the reference's
+        # `preds[keep]` indexing does (pred_masks / pred_rboxes of the mask branch, user fields)
+        boxlike = set()
+        for name, v in preds.get_fields().items():
+            if name in ("pred_boxes", "scores", "pred_classes", "pred_text_prob", "orientations") or name in extra:
+                continue
+            t = v.tensor if isinstance(v, RotatedBoxes) else v
+            if not isinstance(t, torch.Tensor) or t.shape[0] != n:
+                continue
+            if isinstance(v, RotatedBoxes):
+                boxlike.add(name)
+            pad = torch.zeros((1, K_) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            pad[0, :n] = t
+            extra[name] = pad
         cnt = torch.tensor([n], dtype=torch.int32, device=dev)
-        return self.process_padded(boxes, scores, cnt, text, None, [preds.image_size], extra)[0]
+        out = self.process_padded(boxes, scores, cnt, text, None, [preds.image_size], extra)[0]
+        for name in boxlike:
+            out.set(name, RotatedBoxes(out.get(name)))
+        return out
 
     # ------------------------------------------------------------------ host restatement (kept as the readable
     # statement of the semantics and as a cross-check of the kernel in tests; ~56 ms per image)

@@ -59,6 +59,7 @@ BACKBONE_REGISTRY = Registry("BACKBONE")
 PROPOSAL_GENERATOR_REGISTRY = Registry("PROPOSAL_GENERATOR")
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
 ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
+ROI_MASK_HEAD_REGISTRY = Registry("ROI_MASK_HEAD")
 ANCHOR_GENERATOR_REGISTRY = Registry("ANCHOR_GENERATOR")
 RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
 

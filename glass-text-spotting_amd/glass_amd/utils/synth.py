@@ -166,6 +166,15 @@ def make_state_dict(seed: int = 1234, num_classes: int = 1, num_chars: int = 97,
         sd[q + "fc.weight"] = g.normal((num_chars, 256), std=0.5)
         sd[q + "fc.bias"] = g.normal((num_chars,), std=0.1)
         sd[q + "temperature"] = torch.ones(1)
+    if "mask" in parts:        # rotated mask head; own stream, so the other parts are unchanged
+        g = _Gen(seed + 4)
+        p = "roi_heads.mask_head."
+        for k in range(1, 5):
+            _conv(sd, g, p + f"mask_fcn{k}", 256, 256, 3, 3, bias=True)
+        # ConvTranspose2d weight is [Cin, Cout, 2, 2]; each output pixel sees ONE tap -> fan_in = Cin
+        sd[p + "deconv.weight"] = g.normal((256, 256, 2, 2), std=math.sqrt(2.0 / 256))
+        sd[p + "deconv.bias"] = g.normal((256,), std=0.1)
+        _conv(sd, g, p + "predictor", num_classes, 256, 1, 1, bias=True, gain=2.0)
     return sd
 
 

@@ -220,6 +220,23 @@ int glass_mean_over_h(const float* x, float* y, int R, int H, int W, int C, glas
  * The host packs once at checkpoint load (any tensor library can do it:
  *   W.view(rows, K/4, 4).permute(1, 0, 2).contiguous()).                                   */
 
+/* ------------------------------------------------------------------ rotated mask branch (inference)
+ * MaskRotatedRecognizerHybridHead._forward_mask + d2 MaskRCNNConvUpsampleHead + mask_rcnn_inference
+ * (glass/modeling/fusion/recognizers_hybrid_head.py:378-442,595-606; rotated_mask_head.py:409-442): the pooler
+ * is glass_roi_align_rotated (14x14 over p2..p6), the four 3x3 convs and the 1x1 predictor are
+ * glass_conv2d_nhwc / glass_conv3x3_winograd_nhwc, ConvTranspose2d(k=2,s=2)+ReLU is a 1x1 conv to 4*C channels
+ * (weight rows ordered (a*2+b)*C + c for output offset (a,b)) followed by glass_pixel_shuffle2x_nhwc:
+ *   y[n, 2h+a, 2w+b, c] = x[n, h, w, (a*2+b)*C + c],  x [N,H,W,4C] -> y [N,2H,2W,C].                      */
+int glass_pixel_shuffle2x_nhwc(const float* x, float* y, int N, int H, int W, int C, glass_stream_t stream);
+int glass_sigmoid_inplace(float* x, int64_t n, glass_stream_t stream);
+/* paste_masks_in_image / _do_paste_mask for rotated boxes (glass/postprocess/post_processor_academic.py:187-335,
+ * called from detector_postprocess :167-173): masks [R,M,M] (probabilities), boxes [R,5] (cx,cy,w,h,angle deg,
+ * already scaled to the output resolution) -> out uint8 [R,H,W]; threshold >= 0: 1 where the bilinearly sampled
+ * mask >= threshold else 0 (torch.bool layout); threshold < 0: (value * 255) truncated (the reference's
+ * visualisation mode).                                                                                      */
+int glass_paste_rotated_masks(const float* masks, const float* boxes, int R, int M, int H, int W, float threshold,
+                              uint8_t* out, glass_stream_t stream);
+
 /* ------------------------------------------------------------------ recurrent encoder
  * One bidirectional LSTM layer's recurrence (nn.LSTM gate order i,f,g,o; zero initial
  * state; glass/modeling/recognition/recognizer_encoder.py:123-144).  The input projection
