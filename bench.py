@@ -215,7 +215,7 @@ def main():
         n_launch = sum(f["launches"] for f in fam.values())
         KNAME = {"winograd": "conv3x3_wino_f32 (Winograd F(2x2,3x3), fp32 MFMA)",
                  "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)"}
-        PKEY = {"winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_128x128"}
+        PKEY = {"winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_64x64"}    # direct: its busiest instantiation
         dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time
         # PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate
         # rocprofv3 --pmc runs, gfx950 x2 read correction applied; scripts/pmc_make_summary.py)

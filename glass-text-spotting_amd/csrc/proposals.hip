@@ -214,10 +214,11 @@ extern "C" int glass_rotated_nms_select(const float* boxes, const float* scores,
   p.boxes = boxes; p.scores = scores; p.cat = cat; p.valid_count = valid_count; p.image_hw = image_hw; p.N = N; p.S = S;
   p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.post_topk = post_topk; p.flags = flags;
   p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_index = out_index; p.out_count = out_count;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(nms_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    attr_set = true;
+  static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_select_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  if (attr_rc != 0) {
+    glass_set_error("glass_rotated_nms_select: cannot raise the dynamic LDS limit (hip error %d)", attr_rc);
+    return GLASS_EHIP;
   }
   hipLaunchKernelGGL(nms_select_kernel, dim3(N), dim3(NMS_THREADS), smem, (hipStream_t)stream, p);
   GLASS_CHECK_LAUNCH("glass_rotated_nms_select");
