@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--side", type=int, default=SIDE)
     ap.add_argument("--rois", type=int, default=ROIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="steps in flight (host-side software pipelining over HIP streams, glass_amd/utils/pipeline.py); "
+                         "measured neutral on MI355X: 2 in flight lifts GPU-busy from 96.5 to 98 %% but the co-running "
+                         "conv kernels slow each other down by as much")
     ap.add_argument("--workload", default="e2e", choices=["e2e", "backbone"],
                     help="e2e = BASELINE configs[2] (default, the metric's config); backbone = configs[1] (ResNet50-FPN only)")
     ap.add_argument("--cpu-side", type=int, default=SIDE, help="image side of the bounded CPU-baseline sample")
@@ -141,6 +145,7 @@ def main():
     from glass_amd.distributed import all_gather_records, pack_words
     from glass_amd.postprocess import build_post_processor
     from glass_amd.ops import native as K
+    from glass_amd.utils.pipeline import drive, run_pipelined
     from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
 
     cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", f"cuda:{dev_index}"])
@@ -161,21 +166,32 @@ def main():
     if args.workload == "backbone":
         il = model.preprocess_image(inputs)
 
-    def local_step():
+    def local_step_g():
+        """one step as a generator (glass_amd/utils/pipeline.py): yields where the host reads counts back"""
         if args.workload == "backbone":                           # BASELINE configs[1]: trunk + FPN only
             model.backbone.forward_nhwc(il.nhwc4)
             return torch.zeros((B, 1), device=dev)
-        model.inference(inputs, override_boxes=boxes)            # list[{"instances": Instances}] (views)
+            yield                                                 # pragma: no cover (makes this a generator)
+        yield from model.inference_g(inputs, override_boxes=boxes)   # list[{"instances": Instances}] (views)
         det = model.last_batch                                    # + the padded device-resident batch
         # word post-processing (merge, thresholds, polygons, text decode + text-score filter) for the 8 images
-        post.process_padded(det.boxes, det.scores, det.counts_dev, det.text, None, out_sizes, {"orientations": det.orient})
+        yield from post.process_padded_g(det.boxes, det.scores, det.counts_dev, det.text, None, out_sizes,
+                                         {"orientations": det.orient})
         return pack_words(post.last_words, max_det, steps_txt)    # fixed-size per-image word records
 
-    def step():
-        rec = local_step()
+    def step_g():
+        rec = yield from local_step_g()
         if dist is not None and backend != "nccl":
             return all_gather_records(rec.cpu())
         return all_gather_records(rec)
+
+    def local_step():
+        return drive(local_step_g())
+
+    def run_steps(n):
+        """n steps, `--pipeline` of them in flight (each on its own stream; host segments interleaved in a fixed
+        order, so every rank issues its all_gathers in the same order)"""
+        run_pipelined([step_g] * n, depth=args.pipeline, device=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -183,12 +199,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -253,7 +267,8 @@ def main():
                        f"BASELINE.json configs[1]: ResNet50-FPN backbone only, bs={B}/GPU, {args.side}x{args.side}, fp32",
                        "images_per_gpu_per_step": B, "rois_per_image": args.rois, "proposals_per_image": 100,
                        "weights": "random-init (seed 1234), reference architecture",
-                       "parallelism": f"image-shard x{world}, 1 all_gather of result records/step"},
+                       "parallelism": f"image-shard x{world}, 1 all_gather of result records/step",
+                       "steps_in_flight": args.pipeline},
             "images_per_sec_per_gpu": value / world,
             "roofline": {"bound": "mfma", "kernel": ent["kernel"],
                          # `achieved` counts the multiplies the kernel really issues to the matrix cores, so that

@@ -22,6 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from ...utils.module import InferenceModule
+from ...utils.pipeline import ReadBack, drive
 
 from ...ops import native as K
 from ...structures.core import ImageList, Instances, RotatedBoxes, ShapeSpec
@@ -213,13 +214,19 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
     def forward_batched(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor,
                         prop_counts: torch.Tensor, image_sizes: List[Tuple[int, int]],
                         override_boxes: Optional[List[torch.Tensor]] = None) -> BatchedDetections:
+        return drive(self.forward_batched_g(img_nhwc4, feats, prop_boxes, prop_counts, image_sizes, override_boxes))
+
+    def forward_batched_g(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor,
+                          prop_counts: torch.Tensor, image_sizes: List[Tuple[int, int]],
+                          override_boxes: Optional[List[torch.Tensor]] = None):
+        """Generator form (utils/pipeline.py): yields a ReadBack where the host needs the detection counts."""
         device = prop_boxes.device
         hw = torch.tensor(image_sizes, dtype=torch.int32, device=device)
         ob, os_, oi, orient2, oc = self.box_branch_batched(feats, prop_boxes, prop_counts, hw)
         orient = None
         if orient2 is not None:
             orient = torch.gather(orient2, 1, oi.long().unsqueeze(-1).expand(-1, -1, 2))
-        counts = oc.cpu().tolist()           # the one host sync of the step: per-image detection counts
+        counts = (yield ReadBack(oc))[0].tolist()     # host read-back: per-image detection counts size the recognizer batch
         det = BatchedDetections(ob, os_, orient, oc, counts, image_sizes)
         if override_boxes is not None:
             # synthetic-workload hook (bench / teacher-forced parity): recognise these boxes instead

@@ -17,6 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from ...utils.module import InferenceModule
+from ...utils.pipeline import ReadBack, drive
 
 from ...checkpoint import load_checkpoint_file
 from ...ops import native as K
@@ -85,33 +86,42 @@ class GeneralizedRCNN(InferenceModule):
 
     def inference(self, batched_inputs: List[Dict], detected_instances: Optional[List[Instances]] = None,
                   do_postprocess: bool = True, override_boxes: Optional[List[torch.Tensor]] = None):
+        return drive(self.inference_g(batched_inputs, detected_instances, do_postprocess, override_boxes))
+
+    def inference_g(self, batched_inputs: List[Dict], detected_instances: Optional[List[Instances]] = None,
+                    do_postprocess: bool = True, override_boxes: Optional[List[torch.Tensor]] = None):
+        """Generator form of `inference` (utils/pipeline.py): yields a ReadBack wherever the host needs counts;
+        `inference` drives it synchronously, `pipeline.run_pipelined` keeps several steps in flight.  Runs under the
+        driver's torch.no_grad()."""
         assert not self.training
         if not self._loaded:
             raise RuntimeError("no weights loaded: call load_state_dict()/load_checkpoint() first")
-        with torch.no_grad():
-            images = self.preprocess_image(batched_inputs)
-            feats = self.backbone.forward_nhwc(images.nhwc4)
-            if detected_instances is None:
-                hw = torch.tensor(images.image_sizes, dtype=torch.int32, device=self._device)
-                rpn_in = [feats[f] for f in self.proposal_generator.in_features]
-                pboxes, _plogits, pcounts = self.proposal_generator.forward_batched(rpn_in, hw)
-                det = self.roi_heads.forward_batched(images.nhwc4, feats, pboxes, pcounts, images.image_sizes,
-                                                     override_boxes=override_boxes)
-                if do_postprocess:
-                    return self._postprocess_batched(det, batched_inputs, images.image_sizes)
-                self.last_batch = det
-                return det.to_instances()
-            detected_instances = [x.to(self._device) for x in detected_instances]
-            results = self.roi_heads._recognize_into(images.nhwc4, feats, detected_instances)
+        images = self.preprocess_image(batched_inputs)
+        feats = self.backbone.forward_nhwc(images.nhwc4)
+        if detected_instances is None:
+            hw = torch.tensor(images.image_sizes, dtype=torch.int32, device=self._device)
+            rpn_in = [feats[f] for f in self.proposal_generator.in_features]
+            pboxes, _plogits, pcounts = self.proposal_generator.forward_batched(rpn_in, hw)
+            det = yield from self.roi_heads.forward_batched_g(images.nhwc4, feats, pboxes, pcounts, images.image_sizes,
+                                                              override_boxes=override_boxes)
             if do_postprocess:
-                return self._postprocess(results, batched_inputs, images.image_sizes)
-            return results
+                return (yield from self._postprocess_batched_g(det, batched_inputs, images.image_sizes))
+            self.last_batch = det
+            return det.to_instances()
+        detected_instances = [x.to(self._device) for x in detected_instances]
+        results = self.roi_heads._recognize_into(images.nhwc4, feats, detected_instances)
+        if do_postprocess:
+            return self._postprocess(results, batched_inputs, images.image_sizes)
+        return results
 
     # small-box filter of GlassRCNN._postprocess; the stock d2 GeneralizedRCNN has none
     _filter_small = False
     _min_box_dim = 0.0
 
     def _postprocess_batched(self, det, batched_inputs, image_sizes):
+        return drive(self._postprocess_batched_g(det, batched_inputs, image_sizes))
+
+    def _postprocess_batched_g(self, det, batched_inputs, image_sizes):
         """`_postprocess` for the whole step in one kernel (ops.native.detections_finalize) + one read of
         the N surviving counts; per-image Instances are views of the padded outputs."""
         from ..fusion.recognizers_hybrid_head import BatchedDetections
@@ -134,7 +144,7 @@ class GeneralizedRCNN(InferenceModule):
             # the same ordered compaction for the mask rows (the kernel's "text" slot carries any per-RoI payload)
             _, _, _, om, _ = K.detections_finalize(det.boxes, det.scores, None, det.masks[:, 0].contiguous(), det.counts_dev,
                                                    roi_start, scale_xy, out_hw, float(self._min_box_dim), self._filter_small)
-        counts = oc.cpu().tolist()
+        counts = (yield ReadBack(oc))[0].tolist()
         post = BatchedDetections(ob, os_, oo, oc, counts, out_sizes)
         post.text = ot
         self.last_batch = post

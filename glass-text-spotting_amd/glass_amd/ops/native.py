@@ -100,6 +100,7 @@ def _winograd_weights(w: torch.Tensor) -> torch.Tensor:
         cache.move_to_end(key)
         return ent[1]
     u = winograd_pack(w)
+    torch.cuda.current_stream().synchronize()      # once per weight: other streams (pipelined steps) may use it next
     cache[key] = (w, u, w._version)
     if len(cache) > _WINO["max"]:
         cache.popitem(last=False)

@@ -111,6 +111,10 @@ class PostProcessorRotatedBoxes:
                 float(self.minimal_ioa_thresh), float(self.text_threshold if self.text_threshold is not None else 0.0)]
 
     def process_padded(self, boxes, scores, counts_dev, text, scale_xy, image_sizes, extra=None):
+        from ..utils.pipeline import drive
+        return drive(self.process_padded_g(boxes, scores, counts_dev, text, scale_xy, image_sizes, extra))
+
+    def process_padded_g(self, boxes, scores, counts_dev, text, scale_xy, image_sizes, extra=None):
         """All images of a step in ONE kernel (ops.native.postprocess_words) + one read of the compact
         results.  boxes [N,K,5], scores [N,K], text [N,K,T,C]|None (None: no text filter), scale_xy [N,2]|None.
         `extra`: dict name -> padded [N,K,...] tensors gathered along with the survivors."""
@@ -119,9 +123,12 @@ class PostProcessorRotatedBoxes:
         stop = self.text_encoder.character.index("[s]") if use_text else 1
         out = K.postprocess_words(boxes, scores, counts_dev, text if use_text else None, scale_xy, self._thresholds(), stop)
         self.last_words = out              # padded device tensors of this call (distributed.pack_words)
-        counts = out["count"].cpu().tolist()
-        chars = out["char"].cpu().numpy() if use_text else None
-        tlen = out["text_len"].cpu().tolist() if use_text else None
+        from ..utils.pipeline import ReadBack
+        if use_text:          # one read-back (generator form: utils/pipeline.py) of counts, characters and lengths
+            h_count, h_char, h_len = yield ReadBack(out["count"], out["char"], out["text_len"])
+            counts, chars, tlen = h_count.tolist(), h_char.numpy(), h_len.tolist()
+        else:
+            counts, chars, tlen = (yield ReadBack(out["count"]))[0].tolist(), None, None
         results = []
         for n, size in enumerate(image_sizes):
             c = counts[n]

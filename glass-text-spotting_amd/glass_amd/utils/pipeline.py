@@ -1,0 +1,107 @@
+"""Host-side software pipelining of inference steps.
+
+A step has three places where the host must read a few integers back from the GPU before it can size the next
+stage (detection counts -> recognizer batch; surviving counts -> Instances views; word counts / characters).
+Run one step at a time and the GPU idles ~2 ms of 42 around those reads while Python refills the launch queue,
+and the latency-bound tail kernels (NMS, finalize, word post-processing) run alone on the chip.
+
+The step functions are therefore written as generators that `yield ReadBack(tensor, ...)` where they used to call
+`.cpu()`: `drive()` runs one synchronously (the plain API), `run_pipelined()` keeps `depth` steps in flight, each on
+its own HIP stream, advancing them round-robin one segment at a time - while the host waits for step k's
+read-back, step k+1's kernels are already queued, and k's tail overlaps k+1's backbone.
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Callable, Generator, Iterable, List, Optional
+
+import torch
+
+
+class ReadBack:
+    """Request to copy small device tensors to the host.  `start()` enqueues the copies (pinned memory,
+    non-blocking) and an event on the current stream; `wait()` blocks on that event and returns the host tensors."""
+
+    def __init__(self, *tensors: torch.Tensor):
+        self.tensors = tensors
+        self.host: Optional[List[torch.Tensor]] = None
+        self.event: Optional[torch.cuda.Event] = None
+
+    def start(self) -> "ReadBack":
+        self.host = []
+        for t in self.tensors:
+            if t.is_cuda:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+            else:
+                h = t
+            self.host.append(h)
+        if any(t.is_cuda for t in self.tensors):
+            self.event = torch.cuda.Event()
+            self.event.record()
+        return self
+
+    def wait(self) -> List[torch.Tensor]:
+        if self.event is not None:
+            self.event.synchronize()
+        return self.host
+
+
+def drive(gen: Generator):
+    """Run a step generator to completion, serving each read-back immediately (the synchronous API)."""
+    # grad mode is thread-global state: it is set around every segment here (a `with torch.no_grad()` that spans a
+    # `yield` inside the generator would leak into / be clobbered by the other in-flight steps)
+    try:
+        with torch.no_grad():
+            req = next(gen)
+        while True:
+            host = req.start().wait()
+            with torch.no_grad():
+                req = gen.send(host)
+    except StopIteration as e:
+        return e.value
+
+
+def run_pipelined(make_steps: Iterable[Callable[[], Generator]], depth: int = 2, device=None) -> list:
+    """Run the step generators produced by `make_steps` with up to `depth` in flight; returns their results in
+    order.  Every step runs under its own stream (round-robin over `depth` streams); the host work of the
+    in-flight steps is interleaved segment by segment in a fixed order, so ranks of a multi-GPU job that run the
+    same schedule also issue their collectives in the same order."""
+    if depth <= 1:
+        return [drive(mk()) for mk in make_steps]
+    streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
+    main = torch.cuda.current_stream(device)
+    todo = deque(enumerate(make_steps))
+    active = deque()                 # [index, generator, stream, pending ReadBack | None]
+    results = {}
+
+    def advance(slot) -> bool:
+        idx, gen, st, req = slot
+        with torch.cuda.stream(st), torch.no_grad():
+            try:
+                nxt = next(gen) if req is None else gen.send(req.wait())
+                slot[3] = nxt.start()
+                return True
+            except StopIteration as e:
+                results[idx] = e.value
+                return False
+
+    while todo or active:
+        while todo and len(active) < depth:
+            idx, mk = todo.popleft()
+            st = streams[idx % depth]
+            st.wait_stream(main)                      # inputs prepared on the caller's stream
+            slot = [idx, None, st, None]
+            with torch.cuda.stream(st):
+                slot[1] = mk()
+            if advance(slot):
+                active.append(slot)
+            else:
+                main.wait_stream(st)
+        if active:
+            slot = active.popleft()
+            if advance(slot):
+                active.append(slot)
+            else:
+                main.wait_stream(slot[2])
+    return [results[i] for i in sorted(results)]
