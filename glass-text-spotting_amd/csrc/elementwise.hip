@@ -168,3 +168,23 @@ extern "C" int glass_mean_over_h(const float* x, float* y, int R, int H, int W, 
   GLASS_CHECK_LAUNCH("glass_mean_over_h");
   return GLASS_OK;
 }
+
+// ---------------------------------------------------------------- a *= b (SimpleAttention gate, fusion_modules.py:183)
+__global__ void mul_inplace_kernel(float4* __restrict__ a, const float4* __restrict__ b, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 x = a[i];
+    const float4 y = b[i];
+    x.x *= y.x; x.y *= y.y; x.z *= y.z; x.w *= y.w;
+    a[i] = x;
+  }
+}
+
+extern "C" int glass_mul_inplace(float* a, const float* b, int64_t n, glass_stream_t stream) {
+  GLASS_CHECK_ARG((a && b) || n == 0, "glass_mul_inplace: null pointer");
+  GLASS_CHECK_ARG(n >= 0 && n % 4 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0, "glass_mul_inplace: n %% 4 == 0 and 16-byte alignment required");
+  if (n == 0) return GLASS_OK;
+  hipLaunchKernelGGL(mul_inplace_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<float4*>(a), reinterpret_cast<const float4*>(b), (long)(n / 4));
+  GLASS_CHECK_LAUNCH("glass_mul_inplace");
+  return GLASS_OK;
+}

@@ -2,7 +2,10 @@
 
 Mirrors reference glass/modeling/fusion/fusion_modules.py: `MultiAspectGCAttention` (:22-157,
 pooling 'att', fusion 'channel_add') and `P2P3Fusion` (:250-286), plus the registry/builder
-(:10-18).  Unused variants (SimpleAttention, LocalOnly, Conv1x1) are out of scope.
+(:10-18), and the three variants no shipped config selects - `SimpleAttention`, `LocalOnly`, `Conv1x1`
+(:160-247).  The head hands every fusion module the channel-INTERLEAVED concat (local on even,
+global on odd channels - free for MultiAspectGCAttention's `order`); the variants consume the reference's
+plain cat(local, global), so their weight columns are permuted to the interleaved order once at load.
 """
 from __future__ import annotations
 
@@ -66,6 +69,88 @@ class MultiAspectGCAttention(InferenceModule):
         order[1::2] = torch.arange(C)[C // 2:]
         xi = x[:, order.to(x.device)].permute(0, 2, 3, 1).contiguous()
         return self.forward_interleaved(xi).permute(0, 3, 1, 2)
+
+
+def _interleaved_position(c_total: int) -> torch.Tensor:
+    """position in the interleaved layout of channel k of cat(local, global): local k -> 2k, global k -> 2k+1."""
+    half = c_total // 2
+    k = torch.arange(c_total)
+    return torch.where(k < half, 2 * k, 2 * (k - half) + 1)
+
+
+class _CatFusionBase(InferenceModule):
+    """shared plumbing of the cat(local, global) variants"""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        self.local_ch = cfg.MODEL.LOCAL_FEATURE_EXTRACTOR.NUM_FEATURES
+        self.global_ch = input_shape.channels
+        self.in_channels = self.local_ch + self.global_ch
+        self.out_channels = cfg.MODEL.HYBRID_FUSION.NUM_FEATURES
+        assert self.local_ch == self.global_ch, "the interleaved concat assumes equally wide local / global features"
+        self.w: Dict[str, torch.Tensor] = {}
+
+    def _cols_to_interleaved(self, w2d: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(w2d)
+        out[:, _interleaved_position(self.in_channels)] = w2d
+        return out
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """reference convention: logical NCHW cat(local, global) -> NCHW."""
+        C = x.shape[1]
+        order = torch.zeros(C, dtype=torch.long)
+        order[0::2] = torch.arange(C)[: C // 2]
+        order[1::2] = torch.arange(C)[C // 2:]
+        xi = x[:, order.to(x.device)].permute(0, 2, 3, 1).contiguous()
+        return self.forward_interleaved(xi).permute(0, 3, 1, 2)
+
+
+@HYBRID_FEATURE_FUSION_REGISTRY.register()
+class Conv1x1(_CatFusionBase):
+    """1x1 conv (no bias) over the concat, reference fusion_modules.py:222-247."""
+
+    def import_weights(self, sd, device, prefix: str) -> None:
+        w = sd[prefix + "conv.weight"].float().reshape(self.out_channels, self.in_channels)
+        self.w = {"conv": dev(self._cols_to_interleaved(w).reshape(self.out_channels, 1, 1, self.in_channels), device)}
+
+    def forward_interleaved(self, x: torch.Tensor) -> torch.Tensor:
+        return K.conv2d_nhwc(x, self.w["conv"], None)
+
+
+@HYBRID_FEATURE_FUSION_REGISTRY.register()
+class LocalOnly(_CatFusionBase):
+    """keeps the local half of the concat, reference fusion_modules.py:189-219."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__(cfg, input_shape)
+        assert cfg.MODEL.HYBRID_FUSION.NUM_FEATURES == self.local_ch
+
+    def import_weights(self, sd, device, prefix: str) -> None:
+        self.w = {}
+
+    def forward_interleaved(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.shape[-1] == self.in_channels
+        return x[..., 0::2].contiguous()
+
+
+@HYBRID_FEATURE_FUSION_REGISTRY.register()
+class SimpleAttention(_CatFusionBase):
+    """x <- linear(x) * x over the channel axis (no bias), then a 1x1 conv (no bias), reference
+    fusion_modules.py:160-186.  The linear is a 1x1 conv on the MFMA kernel; both its rows and its columns move to
+    the interleaved channel order so that the gate lines up with x."""
+
+    def import_weights(self, sd, device, prefix: str) -> None:
+        C = self.in_channels
+        wl = self._cols_to_interleaved(sd[prefix + "linear.weight"].float().reshape(C, C))
+        wl_rows = torch.empty_like(wl)
+        wl_rows[_interleaved_position(C)] = wl
+        wc = self._cols_to_interleaved(sd[prefix + "conv.weight"].float().reshape(self.out_channels, C))
+        self.w = {"linear": dev(wl_rows.reshape(C, 1, 1, C), device), "conv": dev(wc.reshape(self.out_channels, 1, 1, C), device)}
+
+    def forward_interleaved(self, x: torch.Tensor) -> torch.Tensor:
+        g = K.conv2d_nhwc(x, self.w["linear"], None)
+        K.mul_(g, x)
+        return K.conv2d_nhwc(g, self.w["conv"], None)
 
 
 class P2P3Fusion(InferenceModule):

@@ -185,6 +185,15 @@ def pixel_shuffle2x_nhwc(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def mul_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _f32c(a, "a"); _f32c(b, "b")
+    if a.shape != b.shape:
+        raise GlassLibraryError(f"mul_: shapes {tuple(a.shape)} vs {tuple(b.shape)}")
+    check(lib().glass_mul_inplace(c_void_p(_dev(a)), c_void_p(_dev(b)), ctypes.c_int64(a.numel()), c_void_p(stream_handle())),
+          "glass_mul_inplace")
+    return a
+
+
 def sigmoid_(x: torch.Tensor) -> torch.Tensor:
     _f32c(x, "x")
     check(lib().glass_sigmoid_inplace(c_void_p(_dev(x)), ctypes.c_int64(x.numel()), c_void_p(stream_handle())),

@@ -220,6 +220,9 @@ int glass_mean_over_h(const float* x, float* y, int R, int H, int W, int C, glas
  * The host packs once at checkpoint load (any tensor library can do it:
  *   W.view(rows, K/4, 4).permute(1, 0, 2).contiguous()).                                   */
 
+/* a[i] *= b[i] (the gate of the `SimpleAttention` fusion variant, glass/modeling/fusion/fusion_modules.py:181-186) */
+int glass_mul_inplace(float* a, const float* b, int64_t n, glass_stream_t stream);
+
 /* ------------------------------------------------------------------ rotated mask branch (inference)
  * MaskRotatedRecognizerHybridHead._forward_mask + d2 MaskRCNNConvUpsampleHead + mask_rcnn_inference
  * (glass/modeling/fusion/recognizers_hybrid_head.py:378-442,595-606; rotated_mask_head.py:409-442): the pooler

@@ -239,3 +239,21 @@ def test_product_refuses_cpu_tensors():
     from glass_amd.ops import native as K
     with pytest.raises(GlassLibraryError):
         K.conv2d_nhwc(torch.zeros(1, 4, 4, 4), torch.zeros(4, 1, 1, 4))
+
+
+# ------------------------------------------------------------------ f4: fusion variants no shipped config selects
+@pytest.mark.parametrize("name", ["SimpleAttention", "Conv1x1", "LocalOnly"])
+def test_fusion_variants_match_reference_golden(name, golden_dir):
+    """reference fusion_modules.py:160-247 run at 32+32 -> 32 channels (oracle/make_golden.py --variants)."""
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.modeling.fusion.fusion_modules import HYBRID_FEATURE_FUSION_REGISTRY
+    from glass_amd.structures.core import ShapeSpec
+    g = _g(golden_dir, "fusion_variants.npz")
+    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"),
+                        ["MODEL.LOCAL_FEATURE_EXTRACTOR.NUM_FEATURES", 32, "MODEL.HYBRID_FUSION.NUM_FEATURES", 32,
+                         "MODEL.HYBRID_FUSION.NAME", name])
+    m = HYBRID_FEATURE_FUSION_REGISTRY.get(name)(cfg, ShapeSpec(channels=32, height=4, width=8))
+    sd = {k[len(name) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ":") and not k.endswith(":y")}
+    m.import_weights({"p." + k: v for k, v in sd.items()}, _dev(), "p.")
+    y = m(torch.from_numpy(g["x"]).to(_dev()))
+    assert _maxdiff(y.cpu().numpy(), g[name + ":y"]) < 1e-4
