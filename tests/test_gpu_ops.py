@@ -248,3 +248,31 @@ def test_rpn_topk_decode_matches_stable_sort(mode):
         assert torch.equal(os_[:, o:o + k].cpu(), srt), f"level {i}: selected logits / order differ"
         np.testing.assert_allclose(ob[:, o:o + k].cpu().numpy(), boxes.numpy(), rtol=1e-5, atol=1e-4)
         assert (ol[:, o:o + k] == i).all()
+
+
+def test_winograd_random_shape_sweep():
+    """24 seeded random shapes (tiny maps, H or W = 1, odd sizes, ragged tile counts, several channel blocks) :
+    Winograd vs the direct kernel, both through the C ABI."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    rng = np.random.RandomState(123)
+    for it in range(24):
+        N = int(rng.randint(1, 5))
+        H = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 31]))
+        W = int(rng.choice([1, 2, 4, 7, 9, 16, 33, 40]))
+        Cin = int(rng.choice([16, 32, 48, 64, 80]))
+        Cout = int(rng.choice([64, 128, 192]))
+        relu = int(rng.randint(0, 3))
+        use_res = bool(rng.randint(0, 2))
+        g = torch.Generator().manual_seed(1000 + it)
+        x = torch.randn((N, H, W, Cin), generator=g).to(dev)
+        w = (torch.randn((Cout, 3, 3, Cin), generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+        b = (torch.randn((Cout,), generator=g) * 0.1).to(dev)
+        r = torch.randn((N, H, W, Cout), generator=g).to(dev) if use_res else None
+        kw = dict(padding=1, relu=relu, residual=r, res_mode=1 if use_res else 0)
+        yw = K.conv2d_nhwc(x, w, b, winograd=True, **kw)
+        yd = K.conv2d_nhwc(x, w, b, winograd=False, **kw)
+        torch.cuda.synchronize()
+        scale = float(yd.abs().max()) + 1e-6
+        err = float((yw - yd).abs().max())
+        assert err <= 2e-5 * scale, f"case {it}: N={N} H={H} W={W} Cin={Cin} Cout={Cout} relu={relu} res={use_res}: {err / scale:.2e}"
