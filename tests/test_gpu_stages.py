@@ -257,3 +257,19 @@ def test_fusion_variants_match_reference_golden(name, golden_dir):
     m.import_weights({"p." + k: v for k, v in sd.items()}, _dev(), "p.")
     y = m(torch.from_numpy(g["x"]).to(_dev()))
     assert _maxdiff(y.cpu().numpy(), g[name + ":y"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["CNN_V1_1", "CNN_V2_1"])
+def test_recognizer_cnns_match_reference_golden(name, golden_dir):
+    """reference recognizer_backbone.py:34-146 run at 32 channels with eval-mode BN (make_golden --variants); CNN_V1_1
+    is the shipped recognizer CNN (a9), CNN_V2_1 the unused variant (f4)."""
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.modeling.recognition.recognizer_backbone import RECOGNIZER_BACKBONE_REGISTRY
+    from glass_amd.structures.core import ShapeSpec
+    g = _g(golden_dir, "recognizer_cnn_variants.npz")
+    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"))
+    m = RECOGNIZER_BACKBONE_REGISTRY.get(name)(cfg, ShapeSpec(channels=32, height=8, width=16))
+    sd = {"p." + k[len(name) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + ":") and not k.endswith(":y")}
+    m.import_weights(sd, _dev(), "p.")
+    y = m(torch.from_numpy(g["x"]).to(_dev()))
+    assert _maxdiff(y.cpu().numpy(), g[name + ":y"]) < 1e-4

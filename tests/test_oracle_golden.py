@@ -61,3 +61,16 @@ def test_decoder_and_early_break(sd, golden_dir):
     y3 = O.attention_decoder(sd3, torch.from_numpy(g["x_partial"]))
     np.testing.assert_allclose(y3.numpy(), g["y_partial"], rtol=0, atol=1e-5)
     assert (y3[:, 9:] == 0).all() and (y3[:, 8].sum(-1) > 0).all()
+
+
+def test_recognizer_cnn_oracle_matches_reference_module(golden_dir):
+    """a9: oracle.recognizer_cnn vs the reference's CNN_V1_1 run with eval-mode BN (make_golden --variants)."""
+    import numpy as np
+    import os
+    import torch
+    from oracle import glass_cpu as O
+    g = np.load(os.path.join(golden_dir, "recognizer_cnn_variants.npz"))
+    pre = "roi_heads.recognizer_head.backbone."
+    sd = {pre + k[len("CNN_V1_1:"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("CNN_V1_1:") and not k.endswith(":y")}
+    y = O.recognizer_cnn(sd, torch.from_numpy(g["x"]))
+    assert float((y - torch.from_numpy(g["CNN_V1_1:y"])).abs().max()) < 2e-5
