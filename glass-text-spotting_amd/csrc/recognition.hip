@@ -307,15 +307,15 @@ extern "C" int glass_bilstm_recurrence(const float* xg, const float* w_hh_packed
 // stays on device):
 //   dec_fc_att_kernel  (4 RoIs per workgroup): [fc + softmax + argmax of the state h_i -> out[:, i], y_i]
 //                       then [additive attention with h_i -> context, embedding(y_i)] -> inp_{i+1}
-//   dec_gru_kernel     (16 RoIs x 32 hidden units per workgroup): GRU cell on v_mfma_f32_16x16x4_f32,
-//                       every workgroup streams only its 96-row slice of W_ih / W_hh from L2.
+//   dec_gru_kernel     (16 RoIs x GRU_UB hidden units per workgroup): GRU cell on v_mfma_f32_16x16x4_f32,
+//                       every workgroup streams only its 3*GRU_UB-row slice of W_ih / W_hh from L2.
 // A persistent workgroup per RoI group has to pull all 2.6 MB of decoder weights through ONE CU per step
 // (80 us/step measured); spreading each step over the chip costs two launch boundaries (~2 us each).
 constexpr int DEC_D = 256;
 constexpr int DEC_TMAX = 64;
 constexpr int DEC_CMAX = 256;
 constexpr int GRU_RB = 16;
-constexpr int GRU_UB = 32;
+constexpr int GRU_UB = 16;      // hidden units per workgroup: 16 -> 16 x 16 = 256 workgroups at R = 256 (one per CU; 32 left half the chip idle)
 
 struct DecParams {
   const float* x; const float* xproj;
@@ -464,9 +464,9 @@ __global__ __launch_bounds__(256) void dec_fc_att_kernel(DecParams p, const floa
   }
 }
 
-// h_next = GRUCell(inp, h_prev): grid (ceil(R/16), D/32).  The workgroup's 96 gate rows (3 gates x 32 units)
-// are 6 row tiles of 16; each tile has three K-slices of 256 (W_ih[:, :256], W_ih[:, 256:], W_hh) = 18 MFMA
-// jobs of 64 MFMAs, dealt round-robin to the 4 wavefronts; slices are summed in the pointwise phase.
+// h_next = GRUCell(inp, h_prev): grid (ceil(R/16), D/GRU_UB).  The workgroup's 3*GRU_UB gate rows (3 gates x GRU_UB
+// units) are 3*GRU_UB/16 row tiles of 16; each tile has three K-slices of 256 (W_ih[:, :256], W_ih[:, 256:], W_hh):
+// 9*GRU_UB/16 MFMA jobs of 64 MFMAs, dealt round-robin to the 4 wavefronts; slices are summed in the pointwise phase.
 __global__ __launch_bounds__(256) void dec_gru_kernel(DecParams p, const float* __restrict__ hprev, float* __restrict__ hnext) {
   __shared__ __attribute__((aligned(16))) float xin[GRU_RB][2 * DEC_D + 4];
   __shared__ __attribute__((aligned(16))) float hs[GRU_RB][DEC_D + 4];
@@ -487,9 +487,10 @@ __global__ __launch_bounds__(256) void dec_gru_kernel(DecParams p, const float* 
     *reinterpret_cast<float4*>(&hs[r][k4 * 4]) = v;
   }
   __syncthreads();
-  for (int job = wave; job < 18; job += 4) {
+  constexpr int NT = GRU_UB / 16;                           // 16-row MFMA tiles per gate
+  for (int job = wave; job < 9 * NT; job += 4) {
     const int tile = job / 3, part = job - tile * 3;        // part 0/1: W_ih column halves, 2: W_hh
-    const int g = tile >> 1, uh = tile & 1;
+    const int g = tile / NT, uh = tile - g * NT;
     const int row0 = g * DEC_D + ub * GRU_UB + uh * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (part < 2) mfma_rows16<DEC_D>(p.w_ih + part * DEC_D, 2 * DEC_D, row0, &xin[0][part * DEC_D], 2 * DEC_D + 4, lane, acc);
