@@ -31,6 +31,14 @@ __device__ __forceinline__ bool hull_less(Pt A, Pt B) {
 __device__ inline float rotated_iou(const RBox& r1, const RBox& r2) {
   const float area1 = r1.w * r1.h, area2 = r2.w * r2.h;
   if (area1 < 1e-14f || area2 < 1e-14f) return 0.f;
+  {
+    // circumscribed circles disjoint (with slack) -> no intersection point exists -> the algorithm below returns
+    // exactly 0; skipping it matters because its point lists are indexed dynamically (400 B of scratch per lane)
+    // and almost every pair in NMS / the word post-processor is far apart
+    const float dx = r1.cx - r2.cx, dy = r1.cy - r2.cy;
+    const float rr = 0.5f * (sqrtf(r1.w * r1.w + r1.h * r1.h) + sqrtf(r2.w * r2.w + r2.h * r2.h));
+    if (dx * dx + dy * dy > rr * rr * 1.001f + 1e-2f) return 0.f;
+  }
   const float sx = (r1.cx + r2.cx) / 2.0f, sy = (r1.cy + r2.cy) / 2.0f;
   Pt p1[4], p2[4];
   rbox_vertices(r1.cx - sx, r1.cy - sy, r1, p1);
