@@ -32,7 +32,8 @@ struct ConvParams {
   int N, H, W, Cin, Cout, KH, KW, sh, sw, ph, pw, Ho, Wo;
   int ldx, ldy, ycoff, ycs, relu, res_mode, ldr;
   int M, Ktot, nk, tiles_m, tiles_n, vec_epi;
-  unsigned x_bytes, w_bytes;      // buffer sizes for the bounds-checked (FAST) load path
+  unsigned x_bytes, w_bytes;      // buffer sizes for the bounds-checked load paths (0: tensors too large)
+  unsigned magic_cin, magic_kw;   // floor(2^32 / Cin), floor(2^32 / KW) for the per-thread tap decode (MODE 2)
 };
 
 __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
@@ -43,8 +44,12 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK, bool FAST>
+// MODE 0: plain loads, 64-bit addresses (tensors >= 2 GiB).  MODE 1 ("FAST"): Cin % 32 == 0, buffer loads, uniform
+// scalar tap tracking.  MODE 2: any Cin % 4 == 0 (stem, Cin = 4 / 16 first layers), buffer loads, per-thread tap decode
+// by mul-high.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK, int MODE>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
+  constexpr bool FAST = MODE == 1, BUF = MODE != 0;
   constexpr int LDS_LD = BK + 4;
   constexpr int KCH = BK / 4;            // 16-byte chunks per staged row
   constexpr int RPP = 256 / KCH;         // rows staged per pass of the 256 threads
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   unsigned b_voff[B_LOADS];
   __amdgpu_buffer_rsrc_t xr, wr;
   int f_dh = 0, f_dw = 0, f_c0 = 0;          // uniform: tap row / column, first channel of the current k-tile
-  if constexpr (FAST) {
+  if constexpr (BUF) {
     xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 #pragma unroll
@@ -145,6 +150,34 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     f_dh += wrap_w;
   };
 
+  // MODE 2: the k-tile spans several taps (Cin < 32) or straddles them; every thread decodes its own 16-byte chunk
+  // (tap, channel) with two mul-high divisions and goes through the same bounds-checked loads (~50 VALU per k-tile
+  // instead of ~150 for the plain path: two real integer divisions, 64-bit addresses and a 4-component select per load)
+  auto udiv = [](int t, int d, unsigned magic) {
+    int q = d == 1 ? t : (int)__umulhi((unsigned)t, magic);
+    if (t - q * d >= d) ++q;
+    return q;
+  };
+  auto load_tile_buf = [&](int kt) {
+    const int kpos = kt * BK + cc * 4;
+    const bool kvalid = kpos < p.Ktot;
+    const int tap = udiv(kpos, p.Cin, p.magic_cin);
+    const int c = kpos - tap * p.Cin;
+    const int dh = udiv(tap, p.KW, p.magic_kw);
+    const int dw = tap - dh * p.KW;
+    const int koff = ((dh * p.W + dw) * p.ldx + c) * 4 - cc * 16;       // a_off already carries the chunk column
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
+      const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const unsigned off = ok ? (unsigned)(a_off[i] + koff) : OOB;
+      areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      breg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, kvalid ? b_voff[i] : OOB, kt * (BK * 4), 0));
+  };
+
   auto load_tile_generic = [&](int kt) {
     const int kpos = kt * BK + cc * 4;
     const bool kvalid = kpos < p.Ktot;
@@ -171,7 +204,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     }
   };
   auto load_tile = [&](int kt) {
-    if constexpr (FAST) load_tile_fast(kt); else load_tile_generic(kt);
+    if constexpr (MODE == 1) load_tile_fast(kt); else if constexpr (MODE == 2) load_tile_buf(kt); else load_tile_generic(kt);
   };
   auto store_tile = [&](int stage) {
     float* As = smem + stage * STAGE;
@@ -202,9 +235,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   __syncthreads();
   for (int kt = 0; kt < p.nk; ++kt) {
     const bool more = kt + 1 < p.nk;
-    // FAST: unconditional (after the last k-tile the bounds-checked loads just return zeros / unused data),
+    // buffer-load modes: unconditional (after the last k-tile the bounds-checked loads just return zeros / unused data),
     // so the whole k-tile is one scheduling region and the loads can be metered out between the MFMAs below
-    if (FAST || more) load_tile(kt + 1);
+    if (BUF || more) load_tile(kt + 1);
     const int cur = NSTAGE == 2 ? (kt & 1) : 0;
     const float* a_frag = a_frag0 + cur * STAGE;
     const float* b_frag = b_frag0 + cur * STAGE;
@@ -228,7 +261,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
         }
       }
     }
-    if constexpr (FAST) {
+    if constexpr (BUF) {
       // A burst of vector-memory instructions fills the CU's address queue and the wave then sits on its next
       // load instead of issuing an MFMA; one load per PER MFMAs keeps the queue shallow (measured on the
       // Winograd kernel: +10%).
@@ -374,10 +407,12 @@ static int launch_conv_impl(ConvParams& p, hipStream_t stream) {
     return GLASS_EINVAL;
   }
   p.nk = cdiv(p.Ktot, BK);
-  if (p.x_bytes != 0)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, true>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  if (p.x_bytes != 0 && p.Cin % BK == 0)
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  else if (p.x_bytes != 0)
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   else
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, false>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 0>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   GLASS_CHECK_LAUNCH("glass_conv2d_nhwc");
   return GLASS_OK;
 }
@@ -408,11 +443,13 @@ extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const
   p.M = (int)M;
   p.Ktot = d->KH * d->KW * d->Cin;
   {
-    // FAST load path needs whole k-tiles inside one filter tap and 31-bit byte offsets
+    // the buffer-load paths need 31-bit byte offsets (MODE 1 additionally Cin % 32 == 0, checked at launch)
     const long xb = (long)d->N * d->H * d->W * d->ldx * 4, wb = (long)d->Cout * p.Ktot * 4;
-    const bool fast = (d->Cin % 32 == 0) && xb < 0x7fffff00L && wb < 0x7fffff00L;
-    p.x_bytes = fast ? (unsigned)xb : 0u;
-    p.w_bytes = fast ? (unsigned)wb : 0u;
+    const bool small = xb < 0x7fffff00L && wb < 0x7fffff00L;
+    p.x_bytes = small ? (unsigned)xb : 0u;
+    p.w_bytes = small ? (unsigned)wb : 0u;
+    p.magic_cin = (unsigned)(0x100000000ULL / (unsigned long long)d->Cin);
+    p.magic_kw = (unsigned)(0x100000000ULL / (unsigned long long)d->KW);
   }
   p.vec_epi = (d->y_cstride == 1 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && d->Cout % 4 == 0 &&
                ((uintptr_t)y & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
