@@ -11,10 +11,10 @@ import json
 import sys
 
 fetch, write, mfma = (json.load(open(p)) for p in sys.argv[1:4])
-KEYS = {"conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, true>",
-        "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, true>",
-        "conv_igemm_f32_128x64": "conv_igemm_f32<2, 2, 2, 1, 1, 4, 32, true>",
-        "conv_igemm_f32_64x64": "conv_igemm_f32<2, 2, 1, 1, 1, 8, 32, true>"}
+KEYS = {"conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, 1>",
+        "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, 1>",
+        "conv_igemm_f32_128x64": "conv_igemm_f32<2, 2, 2, 1, 1, 4, 32, 1>",
+        "conv_igemm_f32_64x64": "conv_igemm_f32<2, 2, 1, 1, 1, 8, 32, 1>"}
 
 
 def pick(js, sub, counter):
