@@ -289,6 +289,13 @@ def main():
                          "all_conv_launches_per_step": n_launch, "all_conv_ms_per_step": conv_ms,
                          "all_conv_algorithmic_tflops": conv_flops / (conv_ms * 1e-3) / 1e12},
             "whole_step_tflops": conv_flops / (ms_per_step * 1e-3) / 1e12,
+            # north star: throughput "as fraction of the conv-bound roofline" = fp32 MFMA peak / direct-conv FLOPs per
+            # image (0.846 TFLOP at 1024^2, P=100, R=32 -> 186 img/s/GPU); the convs of this very step,
+            # counted the same way, give the per-image figure used here.  > 1 is possible only because the 3x3 layers
+            # run Winograd (2.25x fewer multiplies than the direct-convolution count).
+            "conv_bound_roofline": {"tflop_per_image": conv_flops / B / 1e12,
+                                    "images_per_sec_per_gpu": FP32_MFMA_PEAK_TFLOPS / (conv_flops / B / 1e12),
+                                    "frac": (value / world) / (FP32_MFMA_PEAK_TFLOPS / (conv_flops / B / 1e12))},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_side, args.rois)
