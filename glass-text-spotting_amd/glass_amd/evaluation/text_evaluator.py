@@ -8,8 +8,9 @@ Host-side only (strings, JSON, zip): nothing here touches the GPU.  Mirrors, wit
     `Levenshtein` package is replaced by `levenshtein` below),
   * `TextResultWriter.to_eval_format` / `sort_detection` (:96-239): the RRC "x1,y1,...,xn,yn,####text" files, one
     per image, thresholded, clockwise, zipped as det.zip.
-Not built: `masks_to_polygons` (rasterio + shapely polygoniser of pasted masks, :464-492) - pass your own through
-`masks_to_polygons=`; without it the rotated box polygon is used.  The scoring itself (`text_eval_script`, the
+`masks_to_polygons` (:464-492) is a pixel-edge ring tracer standing in for the rasterio + shapely polygoniser the
+reference uses (absent here); pass it (or your own) through `masks_to_polygons=`, otherwise the rotated box
+polygon is used.  The scoring itself (`text_eval_script`, the
 official RRC script) and dataset catalogues are out of scope.
 """
 from __future__ import annotations
@@ -60,6 +61,71 @@ def rotated_boxes_to_polygons(boxes: np.ndarray) -> np.ndarray:
     p[:, 2, 1] = cy + (h * c + w * s) / 2
     p[:, 3, 1] = cy + (h * c - w * s) / 2
     return p
+
+
+def masks_to_polygons(masks: np.ndarray) -> list:
+    """Largest 4-connected region of each boolean mask as its exterior ring along the pixel edges: what the reference
+    gets from `rasterio.features.shapes` + shapely (`masks_to_polygons`, text_evaluator.py:464-492: keep the polygon of
+    largest area, return `exterior.coords` as [[x, y], ...], closed).  rasterio / GDAL are absent here, so the ring is
+    traced directly [third-party recall: GDAL polygonises 4-connected regions on the pixel-corner lattice]: vertices
+    are pixel corners (x = column, y = row), only corners where the boundary turns are emitted, the ring is closed
+    (first point repeated).  Vertex start / winding are this tracer's own (clockwise in image coordinates);
+    downstream `sort_detection` re-orients rings and the protocol only uses the geometry.  Area ties keep the first
+    region in scan order."""
+    from scipy import ndimage
+    out = []
+    four = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+    for mask in masks:
+        m = np.asarray(mask).astype(bool)
+        lab, n = ndimage.label(m, structure=four)
+        if n == 0:
+            out.append([])
+            continue
+        sizes = np.bincount(lab.ravel())[1:]
+        k = int(np.argmax(sizes)) + 1                       # argmax returns the first maximum
+        reg = np.pad(lab == k, 1)                           # padded: reg[r + 1, c + 1] is pixel (r, c)
+        rows, cols = np.nonzero(reg)
+        r0 = int(rows.min())
+        c0 = int(cols[rows == r0].min())
+        # boundary walk on the corner lattice with the region on the RIGHT hand side (clockwise in image coordinates),
+        # starting at the top-left corner of the top-left-most pixel, heading east.  Directions: 0 E, 1 S, 2 W, 3 N.
+        # At a corner (y, x) the four pixels around it are NW = reg[y-1, x-1], NE = reg[y-1, x], SW = reg[y, x-1],
+        # SE = reg[y, x] (padded coordinates).
+        def px(y, x):
+            return bool(reg[y, x])
+        y, x, d = r0, c0, 0
+        start = (y, x, d)
+        ring = [(x - 1, y - 1)]
+        while True:
+            # advance one edge
+            if d == 0:
+                x += 1
+            elif d == 1:
+                y += 1
+            elif d == 2:
+                x -= 1
+            else:
+                y -= 1
+            nw, ne, sw, se = px(y - 1, x - 1), px(y - 1, x), px(y, x - 1), px(y, x)
+            # candidates in priority order: turn right, straight, turn left (region kept on the right; at a diagonal
+            # pinch the right turn keeps the walk on the same 4-connected region)
+            ahead_right = {0: se, 1: sw, 2: nw, 3: ne}[d]    # pixel ahead on the right-hand side
+            ahead_left = {0: ne, 1: se, 2: sw, 3: nw}[d]     # pixel ahead on the left-hand side
+            if not ahead_right:
+                nd = (d + 1) % 4                              # region ends: turn right around it
+            elif ahead_left:
+                nd = (d + 3) % 4                              # blocked ahead: turn left
+            else:
+                nd = d
+            if nd != d:
+                ring.append((x - 1, y - 1))
+            d = nd
+            if (y, x, d) == start:
+                break
+        if ring[-1] != ring[0]:
+            ring.append(ring[0])
+        out.append([[float(a), float(b)] for a, b in ring])
+    return out
 
 
 def instances_to_coco_json(instances, file_name, text_encoder, onlyRemoveFirstLastCharacter=True,

@@ -92,3 +92,37 @@ def test_polygon_normalisation_lexicon_and_zip_known_answers():
     assert files == {"0000007.txt": ["0,0,9,0,9,4,0,4,####apple"]}
     z = zipfile.ZipFile(io.BytesIO(w.det_zip(files)))
     assert z.namelist() == ["0000007.txt"] and z.read("0000007.txt").decode() == "0,4,9,4,9,0,0,0,####apple\n"
+
+
+def test_masks_to_polygons_ring_tracer_known_answers():
+    """stand-in for rasterio + shapely (absent): exterior ring of the largest 4-connected region on the pixel-corner
+    lattice.  Checked on hand-made shapes and by the shoelace area (= pixel count for hole-free regions)."""
+    from glass_amd.evaluation import masks_to_polygons
+
+    def area(ring):
+        return abs(sum(ring[i][0] * ring[i + 1][1] - ring[i + 1][0] * ring[i][1] for i in range(len(ring) - 1))) / 2
+
+    rect = np.zeros((6, 8), bool); rect[1:4, 2:6] = True
+    assert masks_to_polygons([rect]) == [[[2.0, 1.0], [6.0, 1.0], [6.0, 4.0], [2.0, 4.0], [2.0, 1.0]]]
+    ell = np.zeros((6, 6), bool); ell[1:5, 1:3] = True; ell[3:5, 3:5] = True
+    assert masks_to_polygons([ell]) == [[[1.0, 1.0], [3.0, 1.0], [3.0, 3.0], [5.0, 3.0], [5.0, 5.0], [1.0, 5.0], [1.0, 1.0]]]
+    holed = np.ones((5, 5), bool); holed[2, 2] = False                        # exterior ring only
+    assert masks_to_polygons([holed]) == [[[0.0, 0.0], [5.0, 0.0], [5.0, 5.0], [0.0, 5.0], [0.0, 0.0]]]
+    two = np.zeros((5, 9), bool); two[1:3, 1:3] = True; two[1:4, 5:8] = True    # the larger region wins
+    assert area(masks_to_polygons([two])[0]) == 9
+    diag = np.zeros((4, 4), bool); diag[0, 0] = diag[1, 1] = diag[1, 2] = diag[2, 1] = True   # diagonal contact only
+    assert area(masks_to_polygons([diag])[0]) == 3
+    assert masks_to_polygons([np.zeros((3, 3), bool)]) == [[]]
+    rng = np.random.RandomState(0)
+    from scipy import ndimage
+    for _ in range(20):                                                        # random blobs: area = pixels + holes
+        m = ndimage.binary_opening(rng.rand(24, 24) > 0.45)
+        lab, n = ndimage.label(m)
+        if n == 0:
+            continue
+        k = int(np.argmax(np.bincount(lab.ravel())[1:])) + 1
+        reg = lab == k
+        ring = masks_to_polygons([m])[0]
+        assert ring[0] == ring[-1] and len(ring) >= 5
+        filled = ndimage.binary_fill_holes(reg, structure=np.ones((3, 3)))    # holes = background not 8-connected outside
+        assert area(ring) == int(filled.sum())
