@@ -79,3 +79,23 @@ def test_config4_textocr_stress_shape_runs(sd):
         assert torch.isfinite(inst.pred_text_prob).all() and inst.pred_text_prob.shape[1:] == (26, 97)
     torch.cuda.synchronize()
     assert torch.cuda.max_memory_allocated() < 200 * 2 ** 30
+
+
+def test_config4_textocr_one_image_vs_oracle(sd):
+    """one 1000x1333 image of the TextOCR shape (orientation head off) against the CPU oracle: character
+    probabilities of 12 injected word boxes (the detection stages are compared at this size by config 1)."""
+    import glass_amd
+    from glass_amd.utils.synth import make_boxes, make_image
+    from oracle import glass_cpu as O
+    cfg = _cfg(["MODEL.ORIENTATION_ON", False])
+    sd2 = {k: v for k, v in sd.items() if "orientation_pred" not in k}
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd2)
+    H, W = 1000, 1333
+    img = make_image(61, H, W).permute(2, 0, 1).float().contiguous()
+    boxes = [make_boxes(61, 12, H, W)]
+    out = m.inference([{"image": img.cuda()}], do_postprocess=False, override_boxes=[boxes[0].cuda()])[0]
+    ref = O.glass_inference(sd2, [img], cfg, injected_boxes=boxes)[0]
+    p, q = out.pred_text_prob.cpu().numpy(), ref["pred_text_prob"].numpy()
+    assert p.shape == q.shape == (12, 26, 97)
+    assert np.abs(p - q).max() < 5e-3 and (p.argmax(-1) == q.argmax(-1)).mean() > 0.99
