@@ -183,8 +183,6 @@ class GlassRCNN(GeneralizedRCNN):
         self.drop_overlapping_boxes = pp.DROP_OVERLAPPING if hasattr(pp, "DROP_OVERLAPPING") else None
         self.ioa_threshold = pp.IOA_THRESHOLD if hasattr(pp, "IOA_THRESHOLD") else None
         self.valid_score = cfg.INFERENCE_TH_TEST if hasattr(cfg, "INFERENCE_TH_TEST") else 0
-        if self.inflate_ratio or self.drop_overlapping_boxes:
-            raise NotImplementedError("INFLATE_RATIO / DROP_OVERLAPPING (eval-CLI only keys) are not built")
         self._filter_small = bool(self.filter_small_boxes)
         self._min_box_dim = float(self.post_processor.min_box_dim)
 
@@ -195,8 +193,21 @@ class GlassRCNN(GeneralizedRCNN):
             width = inp.get("width", image_size[1])
             if self.filter_small_boxes:
                 r = self.post_processor.filter_small_boxes(r)
+            if self.inflate_ratio:
+                r = self.post_processor.resize_boxes(r, self.inflate_ratio)
+            if self.drop_overlapping_boxes:
+                r = self.post_processor.drop_overlapping_boxes(r, self.ioa_threshold, self.valid_score)
             out.append({"instances": detector_postprocess(r, height, width)})
         return out
+
+    def _postprocess_batched_g(self, det, batched_inputs, image_sizes):
+        # INFLATE_RATIO / DROP_OVERLAPPING (set by no shipped YAML; the eval CLI pins DROP_OVERLAPPING False) are
+        # per-image index logic: take the list-wise path (reference order of operations) instead of the fused kernel
+        if self.inflate_ratio or self.drop_overlapping_boxes:
+            self.last_batch = None
+            return self._postprocess(det.to_instances(), batched_inputs, image_sizes)
+            yield                                          # pragma: no cover (keeps this a generator)
+        return (yield from super()._postprocess_batched_g(det, batched_inputs, image_sizes))
 
 
 def build_model(cfg) -> torch.nn.Module:

@@ -52,6 +52,61 @@ class PostProcessorAcademic(PostProcessorRotatedBoxes):
         self.text_threshold = cfg.POST_PROCESSING.TEXT_THRESHOLD
         self.text_encoder = TextEncoder(cfg)
 
+    @staticmethod
+    def resize_boxes(preds: Instances, ratio: float, axis="both"):
+        """Inflate boxes by `ratio` of their own width / height, then clip (reference :36-62; used by
+        GlassRCNN._postprocess when POST_PROCESSING.INFLATE_RATIO is set)."""
+        if len(preds) == 0:
+            return preds
+        boxes = preds.pred_boxes.tensor
+        if axis == "both":
+            delta_x, delta_y = ratio * boxes[:, 2], ratio * boxes[:, 3]
+        elif axis == "vertical":
+            delta_x, delta_y = 0, ratio * boxes[:, 3]
+        elif axis == "horizontal":
+            delta_x, delta_y = ratio * boxes[:, 2], 0
+        else:
+            raise Exception('Please provide an axis value of either "both"/"horizontal"/"vertical')
+        boxes[:, 2] += delta_x
+        boxes[:, 3] += delta_y
+        preds.pred_boxes.tensor = boxes
+        preds.pred_boxes.clip(preds.image_size)
+        return preds
+
+    @staticmethod
+    def drop_overlapping_boxes(preds: Instances, ioa_threshold: float, valid_score: float, minimal_ioa_thresh=0.01):
+        """Replace both boxes of every strongly overlapping confident pair by the larger one, then NMS at 0.99 drops
+        the duplicate with the lower score (reference :64-116; POST_PROCESSING.DROP_OVERLAPPING).  IoA and NMS run on
+        the HIP kernels (structures/boxes.py); the pair bookkeeping is a few index ops on <= 100 boxes.  As written the
+        reference hands RotatedBoxes objects to its tensor-only pairwise_ioa_rotated (AttributeError on `.shape`); this
+        is the evidently intended computation on the box tensors."""
+        from ..structures.boxes import nms_rotated, pairwise_ioa_rotated
+        if len(preds) == 0:
+            return preds
+        ioa = pairwise_ioa_rotated(preds.pred_boxes.tensor, preds.pred_boxes.tensor)
+        boxes = preds.pred_boxes.tensor
+        scores = preds.scores
+        assert boxes.shape[1] == 5
+        areas = boxes[:, 2] * boxes[:, 3]
+        pairs = torch.nonzero(ioa.fill_diagonal_(0).triu() >= minimal_ioa_thresh)
+        if len(pairs) == 0:
+            return preds
+        min_pair_score = torch.min(scores[pairs[:, 0]], scores[pairs[:, 1]])
+        combined = (min_pair_score >= valid_score) & (ioa[pairs[:, 0], pairs[:, 1]] >= ioa_threshold)
+        if (~combined).all():
+            return preds
+        op = pairs[combined]
+        larger = torch.where((areas[op[:, 0]] > areas[op[:, 1]])[..., None], boxes[op[:, 0]], boxes[op[:, 1]])
+        # duplicate indices: the reference's index_put keeps the LAST write on CPU; done in order here so the
+        # device result is the same deterministic one
+        hb, hl = boxes.cpu(), larger.cpu()
+        for col in (0, 1):
+            for k, i in enumerate(op[:, col].tolist()):
+                hb[i] = hl[k]
+        preds.pred_boxes.tensor = hb.to(boxes.device)
+        keep = nms_rotated(preds.pred_boxes.tensor, preds.scores, iou_threshold=0.99)
+        return preds[keep]
+
     def host_call(self, preds, scale_ratio=1, **kwargs):
         preds = super().host_call(preds)
         texts, text_scores, _ = get_instances_text(preds.pred_text_prob, self.text_encoder)

@@ -211,3 +211,49 @@ def test_runner_batch_with_device_postprocess_equals_single_calls():
         np.testing.assert_allclose(a.pred_boxes.tensor.cpu().numpy(), b.pred_boxes.tensor.cpu().numpy(), atol=1e-4)
         assert a.pred_texts == b.pred_texts
         assert a.pred_polygons.shape == (len(a), 4, 2)
+
+
+def test_postprocess_extras_match_reference_golden(golden_dir):
+    """GlassRCNN._postprocess's optional steps, resize_boxes / drop_overlapping_boxes (reference
+    post_processor_academic.py:36-116, run by oracle/make_golden.py --post), on the device IoA / NMS kernels."""
+    from glass_amd.postprocess.post_processor_academic import PostProcessorAcademic
+    from glass_amd.structures.core import Instances, RotatedBoxes
+    g = np.load(os.path.join(golden_dir, "postprocess_extras.npz"))
+    dev = torch.device("cuda:0")
+    for name in ("a", "b", "c"):
+        inst = Instances((800, 800))
+        inst.pred_boxes = RotatedBoxes(torch.from_numpy(g["drop_in_boxes"]).to(dev))
+        inst.scores = torch.from_numpy(g["drop_in_scores"]).to(dev)
+        ioa_thr, valid = [float(v) for v in g[f"drop_{name}_args"]]
+        out = PostProcessorAcademic.drop_overlapping_boxes(inst, ioa_thr, valid)
+        np.testing.assert_allclose(out.pred_boxes.tensor.cpu().numpy(), g[f"drop_{name}_boxes"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(out.scores.cpu().numpy(), g[f"drop_{name}_scores"], rtol=0, atol=0)
+    for axis in ("both", "vertical", "horizontal"):
+        inst = Instances((400, 600))
+        inst.pred_boxes = RotatedBoxes(torch.tensor([[100.0, 100.0, 80.0, 30.0, 0.0], [590.0, 20.0, 60.0, 40.0, 0.5],
+                                                     [300.0, 390.0, 100.0, 50.0, 30.0]], device=dev))
+        inst.scores = torch.tensor([0.9, 0.8, 0.7], device=dev)
+        out = PostProcessorAcademic.resize_boxes(inst, 0.1, axis)
+        np.testing.assert_allclose(out.pred_boxes.tensor.cpu().numpy(), g[f"resize_{axis}"], rtol=0, atol=1e-4)
+
+
+def test_glass_rcnn_inflate_and_drop_overlapping_keys_run():
+    """POST_PROCESSING.INFLATE_RATIO / DROP_OVERLAPPING route _postprocess through the list-wise path."""
+    import glass_amd
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
+    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"),
+                        ["MODEL.DEVICE", "cuda:0", "POST_PROCESSING.INFLATE_RATIO", 0.1, "POST_PROCESSING.DROP_OVERLAPPING", True,
+                         "POST_PROCESSING.IOA_THRESHOLD", 0.7])
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(make_state_dict(1234))
+    img = make_image(70, 160, 224).permute(2, 0, 1).float().contiguous().cuda()
+    b = make_boxes(70, 6, 160, 224)
+    out = m.inference([{"image": img}], override_boxes=[b.cuda()])[0]["instances"]
+    plain_cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", "cuda:0"])
+    m2 = glass_amd.build_model(plain_cfg)
+    m2.load_state_dict(make_state_dict(1234))
+    ref = m2.inference([{"image": img}], override_boxes=[b.cuda()])[0]["instances"]
+    assert 0 < len(out) <= len(ref)
+    # inflated by 10 % before clipping: never smaller than the plain result's boxes it kept
+    assert float(out.pred_boxes.tensor[:, 2].max()) >= float(ref.pred_boxes.tensor[:, 2].max()) * 0.99
