@@ -40,8 +40,6 @@ class GlassRunner:
         self.max_upscale_ratio = self.cfg.INPUT.MAX_UPSCALE_RATIO
         self.input_format = self.cfg.INPUT.FORMAT
         assert self.input_format in ["RGB", "BGR", "GREY"], self.input_format
-        if self.input_format == "GREY":
-            raise NotImplementedError("GREY input is not built")
         self.text_encoder = TextEncoder(self.cfg)
         self.post_processor = build_post_processor(self.cfg)
 
@@ -57,6 +55,11 @@ class GlassRunner:
     def _image_to_tensor(self, original_image: np.ndarray):
         """uint8 HWC on host -> float CHW on device, resized by the reference policy; one H2D copy
         of the uint8 image and one fused convert+resize kernel."""
+        if self.input_format == "GREY":
+            # reference glass/utils/common_utils.py:29-43 (rgb2grey, three_channels=True), on the host uint8 image as
+            # the reference does: Y'709 weights on channels 0,1,2, truncated to uint8, replicated three times
+            g = np.uint8(0.2125 * original_image[:, :, 0] + 0.7154 * original_image[:, :, 1] + 0.0721 * original_image[:, :, 2])
+            original_image = np.repeat(g[:, :, None], 3, axis=2)
         height, width = original_image.shape[:2]
         scale_ratio = self.get_inference_scale_ratio(original_image.shape)
         if scale_ratio != 1:
