@@ -461,8 +461,10 @@ extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const
   if (force_cfg == 3) return launch_conv_impl<2, 2, 2, 1, 1, 4, 32>(p, s);
   if (force_cfg == 4) return launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);   // 64 x 64, 8 blocks/CU
   if (force_cfg == 5) return launch_conv_impl<1, 4, 1, 1, 1, 6, 32>(p, s);   // 32 x 128
+  if (force_cfg == 6) return launch_conv_impl<4, 1, 1, 3, 1, 4, 32>(p, s);   // 128 x 96
   if (d->Cout <= 32) return launch_conv_impl<4, 1, 1, 1, 1, 4, 32>(p, s);   // 128 x 32
   if (d->Cout <= 64) return launch_conv_impl<2, 2, 2, 1, 1, 4, 32>(p, s);   // 128 x 64
+  if (d->Cout <= 96) return launch_conv_impl<4, 1, 1, 3, 1, 4, 32>(p, s);   // 128 x 96 (the merged 72-channel RPN heads: 0.36 -> 0.26 ms)
   // short K (1x1 convs with Cin <= 256; most carry a fused residual): few k-tiles per block, so the block is mostly
   // prologue + epilogue and the layer is HBM-bound - 64x64 tiles at 8 blocks/CU hide those latencies far better
   // than 3 big blocks (64->256 +residual: 3.1 -> 4.7 TB/s; 128->512: 2.3 -> 3.1; 256->1024: 88 -> 108 TFLOP/s)

@@ -30,6 +30,8 @@ LAYERS = [
     ("res3.conv1 1x1 512->128", 8, 128, 128, 512, 128, 1, 1, 0),
     ("res4.conv1 1x1 1024->256", 8, 64, 64, 1024, 256, 1, 1, 0),
     ("res5.conv3 1x1 512->2048", 8, 32, 32, 512, 2048, 1, 1, 0),
+    ("rpn heads 1x1 256->72 @256", 8, 256, 256, 256, 72, 1, 1, 0),
+    ("rpn heads 1x1 256->72 @128", 8, 128, 128, 256, 72, 1, 1, 0),
 ]
 def timed(fn, it=5):
     fn()
