@@ -473,6 +473,7 @@ extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const
   // few 128x128 tiles (deep small maps, linear layers on <=800 rows): halve the tile height so the
   // grid covers the 256 CUs at least ~2x
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(d->Cout, 128);
+  if (p.M <= 2048 && tiles128 < 640 && d->Cout >= 256) return launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);   // 64 x 64: few-row GEMMs (box head fc on 800 rows)
   if (p.M <= 64 || tiles128 < 640) return launch_conv_impl<1, 4, 2, 1, 1, 4, 32>(p, s);   // 64 x 128
   return launch_conv_impl<2, 2, 2, 2, 1, 3, 32>(p, s);                      // 128 x 128, 3 blocks/CU
   // (measured on MI355X: BK=64 with 2 blocks/CU and a 2-stage LDS pipeline are both within 2% of this)
