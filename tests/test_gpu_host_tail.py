@@ -257,3 +257,34 @@ def test_glass_rcnn_inflate_and_drop_overlapping_keys_run():
     assert 0 < len(out) <= len(ref)
     # inflated by 10 % before clipping: never smaller than the plain result's boxes it kept
     assert float(out.pred_boxes.tensor[:, 2].max()) >= float(ref.pred_boxes.tensor[:, 2].max()) * 0.99
+
+
+def test_pipelined_steps_equal_sequential_steps():
+    """utils/pipeline.run_pipelined (two steps in flight on two streams) returns what one-at-a-time execution does."""
+    import glass_amd
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.utils.pipeline import drive, run_pipelined
+    from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
+    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", "cuda:0"])
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(make_state_dict(1234))
+    dev = torch.device("cuda:0")
+    batches = []
+    for s in range(4):
+        imgs = [make_image(80 + 2 * s + i, 160, 192).permute(2, 0, 1).float().contiguous().to(dev) for i in range(2)]
+        bx = [make_boxes(80 + 2 * s + i, 5, 160, 192).to(dev) for i in range(2)]
+        batches.append(([{"image": im} for im in imgs], bx))
+
+    def make(b):
+        def gen():
+            out = yield from m.inference_g(b[0], override_boxes=b[1])
+            return [o["instances"].pred_text_prob.clone() for o in out], [o["instances"].pred_boxes.tensor.clone() for o in out]
+        return gen
+
+    seq = [drive(make(b)()) for b in batches]
+    torch.cuda.synchronize()
+    pip = run_pipelined([make(b) for b in batches], depth=2, device=dev)
+    torch.cuda.synchronize()
+    for (tp_a, bx_a), (tp_b, bx_b) in zip(seq, pip):
+        for a, b in zip(tp_a + bx_a, tp_b + bx_b):
+            assert torch.equal(a, b)

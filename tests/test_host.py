@@ -208,3 +208,19 @@ def test_word_records_roundtrip():
     assert [len(b["texts"]) for b in back] == [2, 0, 6]
     assert torch.equal(back[2]["boxes"], words["boxes"][2]) and torch.equal(back[0]["polygons"], words["polygons"][0, :2])
     assert back[2]["texts"][2] == "".join(chars[int(c)] for c in words["char"][2, 2, :25]) and back[2]["texts"][1] == ""
+
+
+def test_pipeline_drive_serves_readbacks_in_order():
+    """utils/pipeline.drive: a step generator yields ReadBack requests and receives the host copies back."""
+    import torch
+    from glass_amd.utils.pipeline import ReadBack, drive
+
+    def step(n):
+        a = torch.arange(n)
+        (h,) = yield ReadBack(a)
+        total = int(h.sum())
+        h1, h2 = yield ReadBack(a * 2, a + 1)
+        return total, int(h1.sum()), int(h2.sum()), torch.is_grad_enabled()
+
+    assert drive(step(5)) == (10, 20, 15, False)          # segments run under no_grad
+    assert torch.is_grad_enabled()                          # and the caller's grad mode is restored
