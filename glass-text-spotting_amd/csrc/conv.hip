@@ -34,6 +34,7 @@ struct ConvParams {
   int M, Ktot, nk, tiles_m, tiles_n, vec_epi;
   unsigned x_bytes, w_bytes;      // buffer sizes for the bounds-checked load paths (0: tensors too large)
   unsigned magic_cin, magic_kw;   // floor(2^32 / Cin), floor(2^32 / KW) for the per-thread tap decode (MODE 2)
+  int half_mode;                  // 1: fp16 operands on v_mfma_f32_32x32x16_f16 (glass_conv2d_nhwc_f16)
 };
 
 __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
@@ -47,10 +48,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // MODE 0: plain loads, 64-bit addresses (tensors >= 2 GiB).  MODE 1 ("FAST"): Cin % 32 == 0, buffer loads, uniform
 // scalar tap tracking.  MODE 2: any Cin % 4 == 0 (stem, Cin = 4 / 16 first layers), buffer loads, per-thread tap decode
 // by mul-high.
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK, int MODE>
+// HALF: operands are rounded to fp16 (round to nearest even) when they are staged into LDS and multiplied on
+// v_mfma_f32_32x32x16_f16 (fp32 accumulate, 16x the fp32 matrix rate); storage stays fp32.  Opt-in precision mode
+// (glass_conv2d_nhwc_f16, BASELINE configs[4]); never used by the fp32 path the headline metric is measured on.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK, int MODE, bool HALF>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   constexpr bool FAST = MODE == 1, BUF = MODE != 0;
-  constexpr int LDS_LD = BK + 4;
+  constexpr int LDS_LD = HALF ? BK + 8 : BK + 4;      // elements (halfs / floats) per staged row incl. the conflict pad
   constexpr int KCH = BK / 4;            // 16-byte chunks per staged row
   constexpr int RPP = 256 / KCH;         // rows staged per pass of the 256 threads
   constexpr int BM = WAVES_M * TM * 32;
@@ -61,7 +68,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   // k-tile); measured neutral vs 1 stage on MI355X (the 2 co-resident blocks already overlap), and one
   // stage (36 KiB) keeps more blocks resident, which shortens the last partial wave of tiles.
   constexpr int STAGE = (BM + BN) * LDS_LD;
-  __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
+  constexpr int ESZ = HALF ? 2 : 4;
+  // epilogue staging (fp32, LDS-transposed accumulators) shares the buffer: 64 columns per chunk when they fit
+  constexpr int CW = (NSTAGE * STAGE * ESZ >= BM * 68 * 4 && BN >= 64) ? 64 : 32;
+  constexpr int SMEM_BYTES = NSTAGE * STAGE * ESZ > BM * (CW + 4) * 4 ? NSTAGE * STAGE * ESZ : BM * (CW + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  _Float16* hmem = reinterpret_cast<_Float16*>(smem_raw);
 
   // bijective XCD swizzle: XCD (bid % 8) owns a contiguous chunk of logical tile ids
   const int nblk = gridDim.x, bid = blockIdx.x;
@@ -207,14 +220,26 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     if constexpr (MODE == 1) load_tile_fast(kt); else if constexpr (MODE == 2) load_tile_buf(kt); else load_tile_generic(kt);
   };
   auto store_tile = [&](int stage) {
-    float* As = smem + stage * STAGE;
-    float* Bs = As + BM * LDS_LD;
+    if constexpr (HALF) {
+      _Float16* As = hmem + stage * STAGE;
+      _Float16* Bs = As + BM * LDS_LD;
+      auto to_h4 = [](float4 v) { return h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; };   // v_cvt_f16_f32: RNE
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i)
-      *reinterpret_cast<float4*>(&As[(r0 + RPP * i) * LDS_LD + cc * 4]) = areg[i];
+      for (int i = 0; i < A_LOADS; ++i)
+        *reinterpret_cast<h4*>(&As[(r0 + RPP * i) * LDS_LD + cc * 4]) = to_h4(areg[i]);
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i)
-      *reinterpret_cast<float4*>(&Bs[(r0 + RPP * i) * LDS_LD + cc * 4]) = breg[i];
+      for (int i = 0; i < B_LOADS; ++i)
+        *reinterpret_cast<h4*>(&Bs[(r0 + RPP * i) * LDS_LD + cc * 4]) = to_h4(breg[i]);
+    } else {
+      float* As = smem + stage * STAGE;
+      float* Bs = As + BM * LDS_LD;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+        *reinterpret_cast<float4*>(&As[(r0 + RPP * i) * LDS_LD + cc * 4]) = areg[i];
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i)
+        *reinterpret_cast<float4*>(&Bs[(r0 + RPP * i) * LDS_LD + cc * 4]) = breg[i];
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -229,6 +254,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   const int frag_k = (lane >> 5) * 4;
   const float* a_frag0 = smem + (wm * TM * 32 + frag_row) * LDS_LD + frag_k;
   const float* b_frag0 = smem + BM * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + frag_k;
+  // fp16: lane l supplies 8 consecutive k of row l&31 starting at 8*(l>>5) (one ds_read_b128 = one MFMA operand)
+  const _Float16* a_frag0h = hmem + (wm * TM * 32 + frag_row) * LDS_LD + (lane >> 5) * 8;
+  const _Float16* b_frag0h = hmem + BM * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + (lane >> 5) * 8;
 
   load_tile(0);
   store_tile(0);
@@ -239,6 +267,22 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     // so the whole k-tile is one scheduling region and the loads can be metered out between the MFMAs below
     if (BUF || more) load_tile(kt + 1);
     const int cur = NSTAGE == 2 ? (kt & 1) : 0;
+    if constexpr (HALF) {
+      const _Float16* a_frag = a_frag0h + cur * STAGE;
+      const _Float16* b_frag = b_frag0h + cur * STAGE;
+#pragma unroll
+      for (int g = 0; g < BK / 16; ++g) {
+        h8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8*>(a_frag + i * 32 * LDS_LD + g * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8*>(b_frag + j * 32 * LDS_LD + g * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
     const float* a_frag = a_frag0 + cur * STAGE;
     const float* b_frag = b_frag0 + cur * STAGE;
 #pragma unroll
@@ -261,11 +305,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
         }
       }
     }
+    }
     if constexpr (BUF) {
       // A burst of vector-memory instructions fills the CU's address queue and the wave then sits on its next
       // load instead of issuing an MFMA; one load per PER MFMAs keeps the queue shallow (measured on the
       // Winograd kernel: +10%).
-      constexpr int NL = A_LOADS + B_LOADS, NM = (BK / 8) * 4 * TM * TN, PER = NM / NL;
+      constexpr int NL = A_LOADS + B_LOADS, NM = HALF ? (BK / 16) * TM * TN : (BK / 8) * 4 * TM * TN, PER = NM / NL > 0 ? NM / NL : 1;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -291,7 +336,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     // Vector path (unit channel stride, 16-byte aligned rows): the accumulators are transposed through
     // the (now idle) operand LDS so that every lane handles 4 consecutive channels of one pixel:
     // 16-byte residual loads / output stores, 16 lanes covering 256 contiguous bytes of a row.
-    constexpr int CW = ((BM + BN) * LDS_LD >= BM * 68 && BN >= 64) ? 64 : 32;   // columns per staged chunk
     constexpr int SLD = CW + 4;
     constexpr int NCHUNK = BN / CW;
     constexpr int VPR = CW / 4;                    // float4 per staged row
@@ -396,8 +440,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK>
-static int launch_conv_impl(ConvParams& p, hipStream_t stream) {
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK, bool HALF>
+static int launch_conv_cfg(ConvParams& p, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
@@ -408,17 +452,40 @@ static int launch_conv_impl(ConvParams& p, hipStream_t stream) {
   }
   p.nk = cdiv(p.Ktot, BK);
   if (p.x_bytes != 0 && p.Cin % BK == 0)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 1, HALF>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   else if (p.x_bytes != 0)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 0>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 2, HALF>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  else if constexpr (!HALF)
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 0, false>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+  else {
+    glass_set_error("glass_conv2d_nhwc_f16: tensors of 2 GiB and more are not supported in the fp16 mode");
+    return GLASS_EINVAL;
+  }
   GLASS_CHECK_LAUNCH("glass_conv2d_nhwc");
   return GLASS_OK;
 }
 
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK>
+static int launch_conv_impl(ConvParams& p, hipStream_t stream) {
+  return p.half_mode ? launch_conv_cfg<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, true>(p, stream)
+                     : launch_conv_cfg<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, false>(p, stream);
+}
+
+static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
+                         float* y, glass_stream_t stream, int half_mode);
+
 extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
                                  const float* residual, float* y, glass_stream_t stream) {
+  return conv_dispatch(d, x, w, bias, residual, y, stream, 0);
+}
+
+extern "C" int glass_conv2d_nhwc_f16(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
+                                     const float* residual, float* y, glass_stream_t stream) {
+  return conv_dispatch(d, x, w, bias, residual, y, stream, 1);
+}
+
+static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
+                         float* y, glass_stream_t stream, int half_mode) {
   GLASS_CHECK_ARG(d && x && w && y, "glass_conv2d_nhwc: null pointer");
   GLASS_CHECK_ARG(d->Cin > 0 && d->Cin % 4 == 0, "glass_conv2d_nhwc: Cin=%d must be a positive multiple of 4", d->Cin);
   GLASS_CHECK_ARG(d->ldx % 4 == 0 && d->ldx >= d->Cin, "glass_conv2d_nhwc: ldx=%d", d->ldx);
@@ -433,6 +500,7 @@ extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const
   GLASS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "glass_conv2d_nhwc: x/w must be 16-byte aligned");
   if (d->N == 0) return GLASS_OK;
   ConvParams p;
+  p.half_mode = half_mode;
   p.x = x; p.w = w; p.bias = bias; p.res = residual; p.y = y;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
   p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w; p.Ho = d->Ho; p.Wo = d->Wo;

@@ -65,7 +65,23 @@ def conv_out_size(H, W, KH, KW, stride, padding):
 # Winograd F(2x2,3x3) weights, packed once per weight tensor (glass_winograd_pack_weights) the first time a
 # 3x3/stride-1 layer runs.  Keyed by the weight's storage address; the entry pins the weight tensor so the
 # address cannot be recycled, and is re-packed if the tensor was modified in place (_version).
-_WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": collections.OrderedDict(), "max": 512}
+_WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": collections.OrderedDict(), "max": 512,
+         "precision": os.environ.get("GLASS_CONV_PRECISION", "fp32")}
+
+
+def set_conv_precision(precision: str) -> str:
+    """'fp32' (default; the reference's arithmetic, fp32 MFMA / Winograd) or 'fp16' (operands rounded to fp16, fp16 MFMA
+    with fp32 accumulation, direct kernel only - Winograd's transforms are not fp16 safe).  `GLASS_CONV_PRECISION`
+    sets the initial value.  Returns the previous setting."""
+    if precision not in ("fp32", "fp16"):
+        raise GlassLibraryError(f"unknown conv precision {precision!r}")
+    prev = _WINO["precision"]
+    _WINO["precision"] = precision
+    return prev
+
+
+def conv_precision() -> str:
+    return _WINO["precision"]
 
 
 def last_conv_path() -> str:
@@ -132,7 +148,18 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                  res_mode if residual is not None else 0, residual.shape[-1] if residual is not None else 0)
     if residual is not None:
         _f32c(residual, "residual")
+    if _WINO["precision"] == "fp16" and not winograd:
+        _WINO["last_path"] = "direct_fp16"
+        check(lib().glass_conv2d_nhwc_f16(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
+                                          c_void_p(_dev(bias, "bias") if bias is not None else None),
+                                          c_void_p(_dev(residual, "residual") if residual is not None else None),
+                                          c_void_p(_dev(out, "out")), c_void_p(stream_handle())), "glass_conv2d_nhwc_f16")
+        return out
     use_wino = _WINO["enabled"] if winograd is None else winograd
+    if winograd is None and use_wino and KH == 3:
+        # the Winograd kernel runs one 64-tile x 64-channel workgroup per CU: below ~96 workgroups (FPN p6, batch-2 res5)
+        # the direct kernel's smaller tiles fill the chip better (measured 0.68-0.82x vs 1.15x at 128 workgroups)
+        use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
     if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
         u = _winograd_weights(w)
         _WINO["last_path"] = "winograd"

@@ -64,6 +64,13 @@ typedef struct glass_conv_desc {
 int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
                       const float* residual, float* y, glass_stream_t stream);
 
+/* Same operator with the operands rounded to fp16 (round to nearest even) as they are staged and multiplied on the
+ * fp16 matrix cores with fp32 accumulation (v_mfma_f32_32x32x16_f16, 16x the fp32 matrix rate); x, w, bias, residual
+ * and y stay fp32 in memory.  An opt-in precision mode for BASELINE.json configs[4] ("fp16"): results equal
+ * conv(fp16(x), fp16(w)) accumulated in fp32, NOT the fp32 reference path's 1e-3 bar.  Needs tensors < 2 GiB.   */
+int glass_conv2d_nhwc_f16(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
+                          const float* residual, float* y, glass_stream_t stream);
+
 /* Winograd F(2x2,3x3) form of the same operator for the 3x3 / stride 1 / pad 1 layers (FPN output convs,
  * RPN head conv, every 3x3 of the ResNet trunk and of the local extractor's BasicBlocks, fusion output
  * conv): 2.25x fewer fp32 MFMA multiplies, results equal to glass_conv2d_nhwc to fp32 rounding

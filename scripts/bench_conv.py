@@ -30,6 +30,9 @@ LAYERS = [
     ("res3.conv1 1x1 512->128", 8, 128, 128, 512, 128, 1, 1, 0),
     ("res4.conv1 1x1 1024->256", 8, 64, 64, 1024, 256, 1, 1, 0),
     ("res5.conv3 1x1 512->2048", 8, 32, 32, 512, 2048, 1, 1, 0),
+    ("fpn p5 3x3 256 @32", 8, 32, 32, 256, 256, 3, 1, 1),
+    ("res5-like 3x3 512 @16 B=2", 2, 32, 32, 512, 512, 3, 1, 1),
+    ("local tail 3x3 256 @4x32 R=64", 64, 4, 32, 256, 256, 3, 1, 1),
     ("rpn heads 1x1 256->72 @256", 8, 256, 256, 256, 72, 1, 1, 0),
     ("rpn heads 1x1 256->72 @128", 8, 128, 128, 256, 72, 1, 1, 0),
 ]
@@ -62,4 +65,9 @@ for name, N, H, W, Cin, Cout, k, s, p in LAYERS:
         msw = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y2, winograd=True))
         err = float((y2 - y).abs().max() / y.abs().max())
         line += f" | winograd {msw:8.3f} ms {flops / msw / 1e9:7.1f} TFLOP/s-equivalent  x{ms / msw:.2f}  rel.err {err:.1e}"
+    K.set_conv_precision("fp16")
+    y3 = torch.empty_like(y)
+    msh = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y3))
+    K.set_conv_precision("fp32")
+    line += f" | fp16-mfma {msh:8.3f} ms x{ms / msh:.2f} vs fp32 direct"
     print(line, flush=True)

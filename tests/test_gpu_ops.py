@@ -276,3 +276,51 @@ def test_winograd_random_shape_sweep():
         scale = float(yd.abs().max()) + 1e-6
         err = float((yw - yd).abs().max())
         assert err <= 2e-5 * scale, f"case {it}: N={N} H={H} W={W} Cin={Cin} Cout={Cout} relu={relu} res={use_res}: {err / scale:.2e}"
+
+
+F16_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, relu, res_mode
+    (2, 20, 24, 64, 256, (3, 3), (1, 1), (1, 1), 1, 1),
+    (1, 40, 36, 4, 64, (7, 7), (2, 2), (3, 3), 1, 0),
+    (2, 32, 32, 16, 32, (3, 3), (1, 1), (1, 1), 1, 0),
+    (1, 24, 24, 256, 72, (1, 1), (1, 1), (0, 0), 0, 0),
+    (1, 16, 24, 512, 256, (1, 1), (1, 1), (0, 0), 0, 2),
+    (3, 16, 33, 256, 256, (2, 2), (2, 1), (0, 0), 1, 0),
+    (5, 1, 1, 12544, 2048, (1, 1), (1, 1), (0, 0), 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+def test_conv_fp16_mode_equals_conv_of_fp16_rounded_operands(case):
+    """glass_conv2d_nhwc_f16 (opt-in precision mode): exactly conv(fp16(x), fp16(w)) accumulated in fp32 - compared
+    with torch CPU fp64 on the rounded operands, so only the fp32 accumulation order differs (1e-5 of the scale)."""
+    from glass_amd.ops import native as K
+    N, H, W, Cin, Cout, k, s, p, relu, res_mode = case
+    dev = _dev()
+    x = _rand((N, Cin, H, W), 21)
+    w = _rand((Cout, Cin, k[0], k[1]), 22, (2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    b = _rand((Cout,), 23, 0.1)
+    if Cin == 4:
+        x[:, 3] = 0
+    ref = F.conv2d(x.half().double(), w.half().double(), b.double(), stride=s, padding=p)
+    res = None
+    if res_mode == 1:
+        res = _rand(tuple(ref.shape), 24)
+        ref = ref + res.double()
+    elif res_mode == 2:
+        res = _rand((N, Cout, ref.shape[2] // 2, ref.shape[3] // 2), 24)
+        ref = ref + F.interpolate(res.double(), scale_factor=2.0, mode="nearest")
+    if relu == 1:
+        ref = F.relu(ref)
+    prev = K.set_conv_precision("fp16")
+    try:
+        y = K.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), b.to(dev),
+                          stride=s, padding=p, relu=relu,
+                          residual=None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev), res_mode=res_mode)
+        assert K.last_conv_path() == "direct_fp16"
+    finally:
+        K.set_conv_precision(prev)
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 1e-5 * scale
