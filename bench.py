@@ -37,6 +37,7 @@ BATCH = 8
 SIDE = 1000
 ROIS = 32
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+FP16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (only used by --precision fp16)
 
 
 def parse():
@@ -48,6 +49,10 @@ def parse():
     ap.add_argument("--side", type=int, default=SIDE)
     ap.add_argument("--rois", type=int, default=ROIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+                    help="fp32 (default: the reference's arithmetic, what the metric is quoted on) or fp16 = BASELINE configs[4]'s "
+                         "precision: conv / linear operands rounded to fp16 on the fp16 matrix cores, fp32 accumulate and "
+                         "storage.  An fp16 run is a separate, reduced-precision measurement, never the headline value.")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="steps in flight (host-side software pipelining over HIP streams, glass_amd/utils/pipeline.py); "
                          "measured neutral on MI355X: 2 in flight lifts GPU-busy from 96.5 to 98 %% but the co-running "
@@ -67,7 +72,7 @@ class ConvMeter:
     def __init__(self, K):
         self.K = K
         self.orig = K.conv2d_nhwc
-        self.fam = {"winograd": {"events": [], "algo": 0.0, "exec": 0.0}, "direct": {"events": [], "algo": 0.0, "exec": 0.0}}
+        self.fam = {k: {"events": [], "algo": 0.0, "exec": 0.0} for k in ("winograd", "direct", "direct_fp16")}
 
     def __enter__(self):
         def wrapped(x, w, bias=None, **kw):
@@ -148,7 +153,8 @@ def main():
     from glass_amd.utils.pipeline import drive, run_pipelined
     from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
 
-    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", f"cuda:{dev_index}"])
+    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"),
+                        ["MODEL.DEVICE", f"cuda:{dev_index}", "MODEL.CONV_PRECISION", args.precision])
     sd = make_state_dict(1234)
     model = glass_amd.build_model(cfg)
     model.load_state_dict(sd)
@@ -228,8 +234,11 @@ def main():
         conv_flops = sum(f["algo_flops"] for f in fam.values())
         n_launch = sum(f["launches"] for f in fam.values())
         KNAME = {"winograd": "conv3x3_wino_f32 (Winograd F(2x2,3x3), fp32 MFMA)",
-                 "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)"}
-        PKEY = {"winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_64x64"}    # direct: its busiest instantiation
+                 "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
+                 "direct_fp16": "conv_igemm_f32<..., HALF> (fp16 MFMA implicit-GEMM conv/linear, fp32 accumulate)"}
+        PKEY = {"winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
+                "direct_fp16": "conv_igemm_f16"}
+        PEAK = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else FP16_MFMA_PEAK_TFLOPS
         dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time
         # PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate
         # rocprofv3 --pmc runs, gfx950 x2 read correction applied; scripts/pmc_make_summary.py)
@@ -247,9 +256,9 @@ def main():
             pj = pmc_all.get(PKEY[k], {}) if isinstance(pmc_all.get(PKEY[k], {}), dict) else {}
             return {"kernel": KNAME[k], "launches_per_step": f["launches"], "kernel_ms_per_step": f["ms"],
                     "avg_launch_ms": f["ms"] / f["launches"],
-                    "executed_tflops": f["exec_flops"] / sec / 1e12, "executed_frac": f["exec_flops"] / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "executed_tflops": f["exec_flops"] / sec / 1e12, "executed_frac": f["exec_flops"] / sec / 1e12 / PEAK,
                     "algorithmic_tflops": f["algo_flops"] / sec / 1e12,
-                    "algorithmic_frac": f["algo_flops"] / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "algorithmic_frac": f["algo_flops"] / sec / 1e12 / PEAK,
                     "algorithmic_gflop_per_launch": f["algo_flops"] / f["launches"] / 1e9,
                     "traffic": pj.get("hbm_bytes_per_launch_corrected"), "mfma_util_percent_pmc": pj.get("MfmaUtil_percent")}
 
@@ -259,7 +268,8 @@ def main():
             "metric": "images/sec/GPU end-to-end spotting, 1000x1000, ~32 RoIs; 1/2/4/8 GPU scaling",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "fp32" else "f16 operands, f32 accumulate/storage (reduced precision: not the headline)",
+            "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: backbone + RotatedROIAlign + recognition head, "
                                     f"{args.rois} RoIs/img, bs={B}/GPU, {args.side}x{args.side} (padded to /32), fp32")
                        if args.workload == "e2e" else
@@ -275,7 +285,7 @@ def main():
                          # (frac > 1) because it issues 2.25x fewer multiplies than the direct-convolution count.  The
                          # hardware-utilisation view - the FLOP the kernel really issues to the matrix cores - is
                          # `executed_tflops` / `executed_frac` (cross-checked by the PMC MFMA-busy counter).
-                         "achieved": ent["algorithmic_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "achieved": ent["algorithmic_tflops"], "peak": PEAK, "unit": "TFLOP/s",
                          "frac": ent["algorithmic_frac"],
                          "executed_tflops": ent["executed_tflops"], "executed_frac": ent["executed_frac"],
                          "traffic": ent["traffic"],

@@ -125,6 +125,9 @@ def _recognizer_block(name, backbone, encoder, decoder):
 def add_e2e_config(cfg: CN) -> None:
     """Same keys/values as reference glass/config.py:78-170."""
     cfg.MODEL.RECOGNIZER_ON = False
+    # MI355X build only (not a reference key): "fp32" = the reference's arithmetic; "fp16" = convolutions / linears with
+    # operands rounded to fp16 on the fp16 matrix cores, fp32 accumulate and storage (BASELINE.json configs[4])
+    cfg.MODEL.CONV_PRECISION = "fp32"
     cfg.MODEL.ROI_MASK_HEAD.merge_from_other_cfg(
         _recognizer_block(None, "CNN_V1", "BiLSTMBlock", "ASTER"))
     cfg.MODEL.ROI_MASK_HEAD.MASK_INFERENCE = False

@@ -44,6 +44,7 @@ class GeneralizedRCNN(InferenceModule):
         self.pixel_mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
         self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
         self.input_format = cfg.INPUT.FORMAT
+        self.conv_precision = str(cfg.MODEL.CONV_PRECISION) if hasattr(cfg.MODEL, "CONV_PRECISION") else "fp32"
         self._loaded = False
         self.last_batch = None      # padded device-resident results of the last step (for distributed.pack_padded)
 
@@ -96,6 +97,13 @@ class GeneralizedRCNN(InferenceModule):
         assert not self.training
         if not self._loaded:
             raise RuntimeError("no weights loaded: call load_state_dict()/load_checkpoint() first")
+        prev_precision = K.set_conv_precision(self.conv_precision)
+        try:
+            return (yield from self._inference_body_g(batched_inputs, detected_instances, do_postprocess, override_boxes))
+        finally:
+            K.set_conv_precision(prev_precision)
+
+    def _inference_body_g(self, batched_inputs, detected_instances, do_postprocess, override_boxes):
         images = self.preprocess_image(batched_inputs)
         feats = self.backbone.forward_nhwc(images.nhwc4)
         if detected_instances is None:

@@ -121,3 +121,32 @@ def test_config2_bench_workload_one_image_vs_oracle(sd):
     # the box head ran on the real proposals of the image: same proposal set as the oracle's RPN (teacher-free)
     props = ref["proposals"][0]
     assert len(props) > 0
+
+
+def test_config4_fp16_conv_mode_tracks_the_fp32_path(sd):
+    """BASELINE configs[4] asks for an fp16 run: MODEL.CONV_PRECISION fp16 routes every conv / linear through
+    glass_conv2d_nhwc_f16 (operands rounded to fp16, fp16 MFMA, fp32 accumulate and storage).  The op itself is exact
+    against conv(fp16(x), fp16(w)) (tests/test_gpu_ops.py); here the whole model in that mode stays close to the fp32
+    path on the TextOCR-style cfg: same recognised characters for > 90 % of the steps, mean probability delta < 5e-3."""
+    import glass_amd
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import make_boxes, make_image
+    sd2 = {k: v for k, v in sd.items() if "orientation_pred" not in k}
+    H, W = 480, 640
+    img = make_image(62, H, W).permute(2, 0, 1).float().contiguous().cuda()
+    boxes = [make_boxes(62, 16, H, W).cuda()]
+    outs = {}
+    for prec in ("fp32", "fp16"):
+        cfg = _cfg(["MODEL.ORIENTATION_ON", False, "MODEL.CONV_PRECISION", prec])
+        m = glass_amd.build_model(cfg)
+        m.load_state_dict(sd2)
+        m.inference([{"image": img}], do_postprocess=False, override_boxes=boxes)
+        outs[prec] = (m.last_batch.text.cpu().numpy(), K.last_conv_path())
+        assert K.conv_precision() == "fp32"                       # the model restores the global setting
+    assert outs["fp16"][1] == "direct_fp16" and outs["fp32"][1] in ("direct", "winograd")
+    p, q = outs["fp16"][0], outs["fp32"][0]
+    live = q.sum(-1) > 0
+    # greedy decoding: one flipped character re-routes the rest of that word, so the bound is on agreement and on the
+    # mean, not on the maximum
+    assert (p.argmax(-1)[live] == q.argmax(-1)[live]).mean() > 0.9
+    assert np.abs(p - q).mean() < 5e-3
