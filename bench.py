@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gc-freeze", type=int, default=1, help="gc.freeze() the warm heap after warmup (0 = off)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--side", type=int, default=SIDE)
     ap.add_argument("--rois", type=int, default=ROIS)
@@ -109,8 +110,10 @@ class ConvMeter:
 def cpu_baseline(cfg, sd, side, rois):
     """Bounded CPU sample: the oracle (CPU restatement, kind='port') on ONE image of the workload."""
     from glass_amd.utils.synth import make_boxes, make_image
+    from glass_amd.utils.host import usable_cpus
     from oracle import glass_cpu as O
-    n = torch.get_num_threads()
+    n = usable_cpus()                                             # affinity mask and cgroup CFS quota
+    torch.set_num_threads(n)
     img = make_image(0, side, side).permute(2, 0, 1).float()
     boxes = [make_boxes(0, rois, side, side)]
     t0 = time.perf_counter()
@@ -146,6 +149,8 @@ def main():
             dist.init_process_group(backend)
 
     import glass_amd
+    from glass_amd.utils.host import limit_host_threads
+    limit_host_threads()          # before the first CPU tensor op: the host side is launch glue (utils/host.py)
     from glass_amd.config import get_glass_cfg
     from glass_amd.distributed import all_gather_records, pack_words
     from glass_amd.postprocess import build_post_processor
@@ -206,6 +211,13 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(args.warmup)
+    if args.gc_freeze:
+        # serving-loop hygiene, not skipped work: a generation-2 collection walks every object torch created at
+        # import (~25 ms of host stall every few steps, visible once the step is host-bound); freeze moves the
+        # warm heap to the permanent generation so later collections only look at per-step garbage
+        import gc
+        gc.collect()
+        gc.freeze()
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)

@@ -20,12 +20,14 @@ from ..modeling.recognition.text_encoder import TextEncoder
 from ..ops import native as K
 from ..postprocess import build_post_processor
 from ..structures.core import Instances
+from ..utils.host import limit_host_threads
 
 
 class GlassRunner:
     def __init__(self, model_path: Optional[str], config_path: Optional[str], opts: List[str] = None, post_process=True,
                  cfg=None, state_dict=None):
         self.logger = logging.getLogger(__name__)
+        limit_host_threads()                                  # utils/host.py: the host side is launch glue
         self.cfg = (cfg if cfg is not None else get_glass_cfg(config_path, opts)).clone()
         self.model_path, self.config_path, self.post_process_flag = model_path, config_path, post_process
         self.model = build_model(self.cfg)

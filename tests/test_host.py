@@ -224,3 +224,20 @@ def test_pipeline_drive_serves_readbacks_in_order():
 
     assert drive(step(5)) == (10, 20, 15, False)          # segments run under no_grad
     assert torch.is_grad_enabled()                          # and the caller's grad mode is restored
+
+
+def test_host_thread_cap():
+    """utils/host.py: usable_cpus honours affinity / cgroup quota; limit_host_threads caps and reports the old value"""
+    import os
+    import torch
+    from glass_amd.utils.host import DEFAULT_HOST_THREADS, limit_host_threads, usable_cpus
+    n = usable_cpus()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    before = torch.get_num_threads()
+    try:
+        assert limit_host_threads() == before
+        assert torch.get_num_threads() == min(DEFAULT_HOST_THREADS, n)
+        assert limit_host_threads(1) == min(DEFAULT_HOST_THREADS, n)
+        assert torch.get_num_threads() == 1
+    finally:
+        torch.set_num_threads(before)
