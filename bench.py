@@ -60,6 +60,7 @@ def parse():
                          "conv kernels slow each other down by as much")
     ap.add_argument("--workload", default="e2e", choices=["e2e", "backbone"],
                     help="e2e = BASELINE configs[2] (default, the metric's config); backbone = configs[1] (ResNet50-FPN only)")
+    ap.add_argument("--conv-table", default="", help="write the per-launch conv table of the instrumented step here")
     ap.add_argument("--cpu-side", type=int, default=SIDE, help="image side of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -74,6 +75,7 @@ class ConvMeter:
         self.K = K
         self.orig = K.conv2d_nhwc
         self.fam = {k: {"events": [], "algo": 0.0, "exec": 0.0} for k in ("winograd", "direct", "direct_fp16")}
+        self.layers = []
 
     def __enter__(self):
         def wrapped(x, w, bias=None, **kw):
@@ -91,12 +93,20 @@ class ConvMeter:
             else:
                 f["exec"] += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin
             f["events"].append((e0, e1))
+            self.layers.append((self.K.last_conv_path(), tuple(x.shape), (cout, kh, kw_), kw.get("stride", 1),
+                                kw.get("residual") is not None, algo, e0, e1))
             return y
         self.K.conv2d_nhwc = wrapped
         return self
 
     def __exit__(self, *a):
         self.K.conv2d_nhwc = self.orig
+
+    def table(self):
+        """per-launch rows (call after summary()): path, input shape, (Cout, KH, KW), stride, +residual, ms, TFLOP/s"""
+        rows = [(p, xs, ws, st, res, e0.elapsed_time(e1), algo / e0.elapsed_time(e1) / 1e9)
+                for p, xs, ws, st, res, algo, e0, e1 in self.layers]
+        return sorted(rows, key=lambda r: -r[5])
 
     def summary(self):
         torch.cuda.synchronize()
@@ -241,6 +251,11 @@ def main():
         with ConvMeter(K) as meter:
             local_step()
             fam = meter.summary()
+            if args.conv_table:
+                with open(args.conv_table, "w") as f:
+                    for p_, xs, ws, st, res, ms, tf in meter.table():
+                        f.write(f"{ms:8.3f} ms {tf:7.1f} TF/s  {p_:11s} x{list(xs)} -> Cout {ws[0]} k{ws[1]}x{ws[2]} s{st}"
+                                f"{' +res' if res else ''}\n")
         model.roi_heads.two_stream_local = two
         conv_ms = sum(f["ms"] for f in fam.values())
         conv_flops = sum(f["algo_flops"] for f in fam.values())
