@@ -31,7 +31,7 @@ def _inputs(idx, side=1000):
 
 def test_full_size_batch_independence_determinism_and_invariants(model):
     """1000x1000 (padded 1024^2), 32 injected RoIs: a batch of 2 equals the two single-image runs
-    (images are independent; same padded shape), a rerun is bit-identical, outputs are well-formed."""
+    to fp32 rounding (images are independent; same padded shape), a rerun is bit-identical, outputs are well-formed."""
     from glass_amd.utils.synth import make_boxes
     boxes = [make_boxes(i, 32, 1000, 1000).cuda() for i in (0, 1)]
     both = model.inference(_inputs((0, 1)), do_postprocess=False, override_boxes=boxes)
@@ -40,7 +40,9 @@ def test_full_size_batch_independence_determinism_and_invariants(model):
         assert torch.equal(a.pred_text_prob, b.pred_text_prob), "run-to-run nondeterminism"
     for i in (0, 1):
         one = model.inference(_inputs((i,)), do_postprocess=False, override_boxes=[boxes[i]])[0]
-        np.testing.assert_allclose(one.pred_text_prob.cpu().numpy(), both[i].pred_text_prob.cpu().numpy(), atol=1e-6)
+        # not bitwise: the conv dispatch (tile shape, Winograd vs direct) depends on the batch's tile count, so the
+        # fp32 summation order differs between a batch of 1 and of 2 (observed max 4.5e-6 on probabilities)
+        np.testing.assert_allclose(one.pred_text_prob.cpu().numpy(), both[i].pred_text_prob.cpu().numpy(), atol=2e-5)
         p = both[i].pred_text_prob
         assert p.shape == (32, 26, 97) and torch.isfinite(p).all()
         rowsum = p.sum(-1)
