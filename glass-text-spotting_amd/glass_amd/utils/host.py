@@ -41,11 +41,16 @@ def usable_cpus() -> int:
 
 
 def limit_host_threads(n: int | None = None) -> int:
-    """cap torch's intra-op pool at `n` (default: min(8, usable_cpus()), or $GLASS_HOST_THREADS); returns the previous
-    setting. Call before the first CPU tensor op where possible (the pool is created lazily at that size)."""
+    """cap torch's intra-op pool at `n`; returns the previous setting. Default ($GLASS_HOST_THREADS overrides):
+    min(current setting, 8, usable_cpus() / ranks on this node) - it never raises a limit the launcher already set
+    (torchrun exports OMP_NUM_THREADS=1) and shares the quota between the node's ranks (LOCAL_WORLD_SIZE).
+    Call before the first CPU tensor op where possible (the pool is created lazily at that size)."""
     prev = torch.get_num_threads()
     if n is None:
-        n = int(os.environ.get("GLASS_HOST_THREADS", "0")) or min(DEFAULT_HOST_THREADS, usable_cpus())
+        n = int(os.environ.get("GLASS_HOST_THREADS", "0"))
+        if n <= 0:
+            ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+            n = min(prev, DEFAULT_HOST_THREADS, max(1, usable_cpus() // ranks))
     n = max(1, int(n))
     if n != prev:
         torch.set_num_threads(n)

@@ -236,8 +236,17 @@ def test_host_thread_cap():
     before = torch.get_num_threads()
     try:
         assert limit_host_threads() == before
-        assert torch.get_num_threads() == min(DEFAULT_HOST_THREADS, n)
-        assert limit_host_threads(1) == min(DEFAULT_HOST_THREADS, n)
+        capped = min(before, DEFAULT_HOST_THREADS, n)
+        assert torch.get_num_threads() == capped
+        os.environ["LOCAL_WORLD_SIZE"] = str(4 * n)            # more ranks than cores: one thread each
+        try:
+            limit_host_threads()
+            assert torch.get_num_threads() == 1
+        finally:
+            del os.environ["LOCAL_WORLD_SIZE"]
+        torch.set_num_threads(1)
+        limit_host_threads()                                   # never raises a limit that is already lower
         assert torch.get_num_threads() == 1
+        assert limit_host_threads(2) == 1 and torch.get_num_threads() == 2
     finally:
         torch.set_num_threads(before)
