@@ -30,6 +30,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "glass-text-spotting_amd"))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: RCCL across processes needs this (the boxes export it already)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
