@@ -308,6 +308,7 @@ def main():
                        "parallelism": f"image-shard x{world}, 1 all_gather of result records/step",
                        "steps_in_flight": args.pipeline},
             "images_per_sec_per_gpu": value / world,
+            "hbm_peak_reserved_gb": torch.cuda.max_memory_reserved(dev) / 1e9,   # rank 0, whole run (of 288 GB)
             "roofline": {"bound": "mfma", "kernel": ent["kernel"],
                          # `achieved` = ALGORITHMIC (direct-convolution) FLOP of the kernel's launches / their
                          # measured time, as the contract defines it; for the Winograd kernel this exceeds the MFMA peak
