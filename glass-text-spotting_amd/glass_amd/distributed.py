@@ -17,7 +17,7 @@ Full `[D,T,97]` probability tensors stay on the owning rank (1 MB/image; gather 
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 

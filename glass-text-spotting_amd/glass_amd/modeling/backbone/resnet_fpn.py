@@ -12,7 +12,7 @@ strided view, not a kernel.
 """
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import Dict
 
 import torch
 

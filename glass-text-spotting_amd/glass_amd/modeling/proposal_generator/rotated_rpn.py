@@ -14,7 +14,7 @@ winners per level); the whole selection runs on device with no host sync
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List
 
 import torch
 

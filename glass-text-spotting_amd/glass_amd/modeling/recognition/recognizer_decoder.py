@@ -8,7 +8,7 @@ MFMA GEMM here.
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Optional
 
 import torch
 

@@ -14,7 +14,6 @@ is compared with degrees (:267) is reproduced, not fixed.
 from __future__ import annotations
 
 import logging
-import math
 import time
 
 import numpy as np

@@ -15,7 +15,7 @@ from __future__ import annotations
 import itertools
 import math
 from collections import namedtuple
-from typing import Any, Dict, List, Sequence, Tuple, Union
+from typing import Any, Dict, List, Sequence, Tuple
 
 import torch
 

@@ -9,7 +9,7 @@ registers the same objects into detectron2's own registries when it is importabl
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Dict, Iterator, Optional, Tuple
+from typing import Any, Dict, Iterator, Optional, Tuple
 
 
 class Registry:

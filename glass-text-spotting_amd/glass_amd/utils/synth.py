@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 from collections import OrderedDict
-from typing import Dict, List, Tuple
+from typing import Tuple
 
 import torch
 
