@@ -296,6 +296,252 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wide variant for Cout % 128 == 0, Cin % 32 == 0 (the 256-channel layers = most of the path's 3x3 time):
+// block tile = 32 output tiles x 128 output channels x 16 xi, k-tile = 32 input channels.  Same 256 accumulators
+// (wave w: xi = 4w..4w+3, each 1 x 4 MFMA blocks of 32x32), same 128 KiB of V, but every transformed input value
+// now feeds 128 instead of 64 output channels: per MFMA the transform's VALU work, the patch loads and the LDS
+// writes / reads are halved; the weight-fragment loads double (they were the cheap part: fully coalesced 1 KiB
+// L2 reads).  Weight fragments stream j-major through a 4-slot ring (slot = j; the fragments of the group three
+// ahead are requested while a group's 16 MFMAs issue), which keeps them at 64 registers.
+constexpr int T2 = 32;                        // output tiles per block
+constexpr int N2 = 128;                       // output channels per block
+constexpr int K2 = 32;                        // input channels per k-tile
+constexpr int V2_FLOATS = 16 * T2 * K2;       // 64 KiB per stage
+constexpr int ZLD2 = N2 + 4;
+constexpr int Z2_FLOATS = 4 * 2 * T2 * ZLD2;  // 132 KiB
+constexpr int WINO128_LDS_BYTES = (2 * V2_FLOATS > Z2_FLOATS ? 2 * V2_FLOATS : Z2_FLOATS) * 4;
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino128_f32(WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = logical / p.tiles_n;
+  const int tile_n = logical - tile_m * p.tiles_n;
+  const int t0 = tile_m * T2, n0 = tile_n * N2;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tpi = p.TH * p.TW;
+
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
+
+  // ---- input role: thread = (tile tl, 4-channel chunk of the 32) ----
+  const int chunk = tid & 7, tl = tid >> 3;
+  unsigned voff[16];
+  {
+    const int t = t0 + tl;
+    const bool tv = t < p.ntiles;
+    const int n = fast_div(t, tpi, p.magic_tpi);
+    const int rem = t - n * tpi;
+    const int th = fast_div(rem, p.TW, p.magic_tw);
+    const int tw = rem - th * p.TW;
+    const int h0 = 2 * th - 1, w0 = 2 * tw - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int hi = h0 + r, wi = w0 + c;
+        const bool ok = tv && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        voff[r * 4 + c] = ok ? (unsigned)((((n * p.H + hi) * p.W + wi) * p.ldx + chunk * 4) * 4) : OOB;
+      }
+  }
+  float4 d[16], t[16];
+  auto load_patch1 = [&](int kt, int i) {
+    d[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[i], kt * (K2 * 4), 0));
+  };
+  // V[stage][xi][tile][32]: a row is 128 bytes = half of the 64 banks; the 16-byte slot is XOR-ed with (tile/2)%8,
+  // so the 16 rows a ds_read_b128 / ds_write_b128 service group touches land on 16 different slots of the 256 bytes.
+  float* vdst = smem + tl * K2 + ((chunk ^ ((tl >> 1) & 7)) * 4);
+  auto row_piece = [&](int c) {
+    t[0 + c] = sub4(d[0 + c], d[8 + c]);
+    t[4 + c] = add4(d[4 + c], d[8 + c]);
+    t[8 + c] = sub4(d[8 + c], d[4 + c]);
+    t[12 + c] = sub4(d[4 + c], d[12 + c]);
+  };
+  auto col_piece = [&](int stage, int i, int j) {
+    const float4 v = j == 0 ? sub4(t[i * 4 + 0], t[i * 4 + 2]) : j == 1 ? add4(t[i * 4 + 1], t[i * 4 + 2])
+                   : j == 2 ? sub4(t[i * 4 + 2], t[i * 4 + 1]) : sub4(t[i * 4 + 1], t[i * 4 + 3]);
+    *reinterpret_cast<float4*>(vdst + stage * V2_FLOATS + (i * 4 + j) * (T2 * K2)) = v;
+  };
+
+  // ---- MFMA role: wave wv owns xi = 4 wv + j, tiles 0..31 x channels nb*32.. ----
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][nb][e] = 0.f;
+
+  const int a_sw = ((lane & 31) >> 1) & 7;
+  const float* a_base = smem + (4 * wv * T2 + (lane & 31)) * K2;
+  const int a_kh = lane >> 5;
+  const unsigned b_voff = (unsigned)lane * 16u;
+  float4 bq[4][4];                           // [slot = j][nb]
+  // packed U: [tile_n][kt][xi][g][nb] chunks of 1 KiB (64 lanes x float4)
+  auto load_b1 = [&](int kt, int g, int j, int nb) {
+    const int base = (((tile_n * p.nk + kt) * 16 + 4 * wv + j) * 16 + g * 4 + nb) * 1024;
+    bq[j][nb] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ur, b_voff, base, 0));
+  };
+
+  // prologue: first patch -> V[0], fragments of the first three groups, second patch in flight
+#pragma unroll
+  for (int i = 0; i < 16; ++i) load_patch1(0, i);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) load_b1(0, 0, j, nb);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) row_piece(c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) col_piece(0, i, j);
+  {
+    const int k1 = p.nk > 1 ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) load_patch1(k1, i);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const int cur = kt & 1;
+    const int ktn = kt + 1 < p.nk ? kt + 1 : kt;
+    const int ktnn = kt + 2 < p.nk ? kt + 2 : kt;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 a[4];
+      {
+        const float* af = a_base + cur * V2_FLOATS + (((2 * g + a_kh) ^ a_sw) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(af + j * (T2 * K2));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mm = 0; mm < 64; ++mm) {
+        const int M = g * 64 + mm;                 // position in the k-tile's 256 MFMAs
+        const int j = mm >> 4, s_ = (mm >> 2) & 3, nb = mm & 3;
+        // side work issued BEFORE MFMA M
+        if ((mm & 3) == 0) {                       // weight fragments of the group three ahead, one load per 4 MFMAs
+          const int u3 = g * 4 + j + 3;            // group index within (this, next) k-tile
+          const int g3 = (u3 >> 2) & 3, j3 = u3 & 3;
+          load_b1(u3 >= 16 ? ktn : kt, g3, j3, s_);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if ((M & 7) == 2) {                 // Bt d B of patch kt+1 -> V[cur^1]
+          if (M >= 10 && M < 40) {
+            row_piece((M - 10) >> 3);              // M = 10, 18, 26, 34
+            __builtin_amdgcn_sched_barrier(0);
+          } else if (M >= 42 && M < 42 + 128) {
+            col_piece(cur ^ 1, ((M - 42) >> 3) >> 2, ((M - 42) >> 3) & 3);     // M = 42 .. 162
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else if ((M & 7) == 6 && M >= 46 && M < 46 + 128) {
+          load_patch1(ktnn, (M - 46) >> 3);        // d is free again: patch of k-tile kt+2
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[j], s_), comp(bq[j][nb], s_), acc[j][nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (same algebra as conv3x3_wino_f32; 32 tiles x 128 channels) ----
+  const int c4 = tid & 31, ts = tid >> 5;
+  const int co = n0 + c4 * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + co);
+  long m_base[4];
+  int oh_ok[4], ow_ok[4];
+  float4 rres[16];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int tt = t0 + pass * 8 + ts;
+    const bool tv = tt < p.ntiles;
+    const int n = fast_div(tt, tpi, p.magic_tpi);
+    const int rem = tt - n * tpi;
+    const int th = fast_div(rem, p.TW, p.magic_tw);
+    const int tw = rem - th * p.TW;
+    m_base[pass] = tv ? ((long)n * p.H + 2 * th) * p.W + 2 * tw : -1;
+    oh_ok[pass] = tv ? (1 | ((2 * th + 1 < p.H) ? 2 : 0)) : 0;
+    ow_ok[pass] = tv ? (1 | ((2 * tw + 1 < p.W) ? 2 : 0)) : 0;
+    if (p.res_mode == 1) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const bool ok = ((oh_ok[pass] >> a) & 1) && ((ow_ok[pass] >> b) & 1);
+          const long m = m_base[pass] + (long)a * p.W + b;
+          rres[pass * 4 + b * 2 + a] = *reinterpret_cast<const float4*>(p.res + (ok ? m * p.ldr + co : 0));
+        }
+    }
+  }
+  float* zs = smem;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      const int col = nb * 32 + (lane & 31);
+      const float m0 = acc[0][nb][e], m1 = acc[1][nb][e], m2 = acc[2][nb][e], m3 = acc[3][nb][e];
+      zs[((wv * 2 + 0) * T2 + row) * ZLD2 + col] = m0 + m1 + m2;
+      zs[((wv * 2 + 1) * T2 + row) * ZLD2 + col] = m1 - m2 - m3;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int tile = pass * 8 + ts;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if (!((ow_ok[pass] >> b) & 1)) continue;
+      const float4 z0 = *reinterpret_cast<const float4*>(&zs[((0 * 2 + b) * T2 + tile) * ZLD2 + c4 * 4]);
+      const float4 z1 = *reinterpret_cast<const float4*>(&zs[((1 * 2 + b) * T2 + tile) * ZLD2 + c4 * 4]);
+      const float4 z2 = *reinterpret_cast<const float4*>(&zs[((2 * 2 + b) * T2 + tile) * ZLD2 + c4 * 4]);
+      const float4 z3 = *reinterpret_cast<const float4*>(&zs[((3 * 2 + b) * T2 + tile) * ZLD2 + c4 * 4]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (!((oh_ok[pass] >> a) & 1)) continue;
+        float4 v = a == 0 ? add4(add4(z0, z1), z2) : sub4(sub4(z1, z2), z3);
+        v = add4(v, bv);
+        if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const long m = m_base[pass] + (long)a * p.W + b;
+        if (p.res_mode == 1) v = add4(v, rres[pass * 4 + b * 2 + a]);
+        if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(p.y + m * p.ldy + p.ycoff + co) = v;
+      }
+    }
+  }
+}
+
+// wide layout: [cout/128][cin/32][xi][g][nb][lane][s]  with  cout = 128 tn + 32 nb + (lane&31),  cin = 32 kt + 8 g + 4 (lane>>5) + s
+__global__ void wino128_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
+  const long total = 16L * Cout * Cin;
+  const int nk = Cin / K2;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    long r = o;
+    const int s = (int)(r & 3); r >>= 2;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int nb = (int)(r & 3); r >>= 2;
+    const int g = (int)(r & 3); r >>= 2;
+    const int xi = (int)(r & 15); r >>= 4;
+    const int kt = (int)(r % nk);
+    const int tn = (int)(r / nk);
+    const int co = tn * N2 + nb * 32 + (lane & 31);
+    const int ci = kt * K2 + g * 8 + (lane >> 5) * 4 + s;
+    const int i = xi >> 2, j = xi & 3;
+    const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc += G[i][a] * G[j][b] * (double)w[(((long)co * 3 + a) * 3 + b) * Cin + ci];
+    u[o] = (float)acc;
+  }
+}
+
 // U = G g G^t per (cout, cin), written in the fragment order the kernel streams:
 // [cout/64][cin/16][xi][nb][g][lane][s]  with  cout = 64 tn + 32 nb + (lane&31),  cin = 16 kt + 8 g + 4 (lane>>5) + s
 __global__ void wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
@@ -323,6 +569,12 @@ __global__ void wino_pack_weights_kernel(const float* __restrict__ w, float* __r
   }
 }
 
+// the wide kernel takes every layer whose channel counts allow it (GLASS_WINO128=0: 64x64 blocks everywhere)
+bool wino_wide(int Cout, int Cin) {
+  static const bool enabled = [] { const char* e = getenv("GLASS_WINO128"); return !(e && e[0] == '0'); }();
+  return enabled && Cout % N2 == 0 && Cin % K2 == 0;
+}
+
 }  // namespace
 
 extern "C" int glass_winograd_supported(const glass_conv_desc* d) {
@@ -342,7 +594,10 @@ extern "C" int glass_winograd_pack_weights(const float* w, int Cout, int Cin, fl
                   "glass_winograd_pack_weights: Cout=%d must be a multiple of 64 and Cin=%d a multiple of 16", Cout, Cin);
   const long total = 16L * Cout * Cin;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(wino_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u_packed, Cout, Cin);
+  if (wino_wide(Cout, Cin))
+    hipLaunchKernelGGL(wino128_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u_packed, Cout, Cin);
+  else
+    hipLaunchKernelGGL(wino_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u_packed, Cout, Cin);
   GLASS_CHECK_LAUNCH("glass_winograd_pack_weights");
   return GLASS_OK;
 }
@@ -366,10 +621,11 @@ extern "C" int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float
   const long nt = (long)d->N * p.TH * p.TW;
   GLASS_CHECK_ARG(nt < 0x7fffffffL, "glass_conv3x3_winograd_nhwc: too many tiles");
   p.ntiles = (int)nt;
-  p.nk = d->Cin / WK;
+  const bool wide = wino_wide(d->Cout, d->Cin);
+  p.nk = d->Cin / (wide ? K2 : WK);
   p.ldx = d->ldx; p.ldy = d->ldy; p.ycoff = d->y_coff; p.ldr = d->ldr; p.relu = d->relu; p.res_mode = d->res_mode;
-  p.tiles_m = cdiv(p.ntiles, WT);
-  p.tiles_n = d->Cout / WN;
+  p.tiles_m = cdiv(p.ntiles, wide ? T2 : WT);
+  p.tiles_n = d->Cout / (wide ? N2 : WN);
   p.x_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldx * 4);
   p.magic_tpi = (unsigned)(0x100000000ULL / (unsigned long long)(p.TH * p.TW));
   p.magic_tw = (unsigned)(0x100000000ULL / (unsigned long long)p.TW);
@@ -378,11 +634,16 @@ extern "C" int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float
   GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv3x3_winograd_nhwc: bad grid");
   static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_f32),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES);
-  if (attr_rc != 0) {
-    glass_set_error("glass_conv3x3_winograd_nhwc: cannot reserve %d bytes of LDS (hip error %d)", WINO_LDS_BYTES, attr_rc);
+  static int attr_rc2 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino128_f32),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WINO128_LDS_BYTES);
+  if (attr_rc != 0 || attr_rc2 != 0) {
+    glass_set_error("glass_conv3x3_winograd_nhwc: cannot reserve %d bytes of LDS (hip error %d / %d)", WINO_LDS_BYTES, attr_rc, attr_rc2);
     return GLASS_EHIP;
   }
-  hipLaunchKernelGGL(conv3x3_wino_f32, dim3((unsigned)nblk), dim3(256), WINO_LDS_BYTES, (hipStream_t)stream, p);
+  if (wide)
+    hipLaunchKernelGGL(conv3x3_wino128_f32, dim3((unsigned)nblk), dim3(256), WINO128_LDS_BYTES, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(conv3x3_wino_f32, dim3((unsigned)nblk), dim3(256), WINO_LDS_BYTES, (hipStream_t)stream, p);
   GLASS_CHECK_LAUNCH("glass_conv3x3_winograd_nhwc");
   return GLASS_OK;
 }
