@@ -27,6 +27,8 @@
 #include "common.h"
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -64,6 +66,15 @@ __device__ __forceinline__ int fast_div(int t, int d, unsigned magic) {
   int q = d == 1 ? t : (int)__umulhi((unsigned)t, magic);
   if (t - q * d >= d) ++q;
   return q;
+}
+
+// compile-time loops: the issue order below is written as straight-line code with static register indices
+template <int I> using ic = std::integral_constant<int, I>;
+template <int... Is, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(ic<Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
 __device__ __forceinline__ float comp(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
@@ -411,41 +422,44 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino128_f32(WinoParams p) {
     const int cur = kt & 1;
     const int ktn = kt + 1 < p.nk ? kt + 1 : kt;
     const int ktnn = kt + 2 < p.nk ? kt + 2 : kt;
+    float4 a[2][4];
+    auto read_a = [&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      const float* af = a_base + cur * V2_FLOATS + (((2 * g + a_kh) ^ a_sw) * 4);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 a[4];
-      {
-        const float* af = a_base + cur * V2_FLOATS + (((2 * g + a_kh) ^ a_sw) * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(af + j * (T2 * K2));
-      }
+      for (int j = 0; j < 4; ++j) a[g & 1][j] = *reinterpret_cast<const float4*>(af + j * (T2 * K2));
+    };
+    read_a(ic<0>{});
+    static_for<4>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mm = 0; mm < 64; ++mm) {
-        const int M = g * 64 + mm;                 // position in the k-tile's 256 MFMAs
-        const int j = mm >> 4, s_ = (mm >> 2) & 3, nb = mm & 3;
+      static_for<64>([&](auto mm_) {
+        constexpr int mm = decltype(mm_)::value;
+        constexpr int M = g * 64 + mm;             // position in the k-tile's 256 MFMAs
+        constexpr int j = mm >> 4, s_ = (mm >> 2) & 3, nb = mm & 3;
         // side work issued BEFORE MFMA M
-        if ((mm & 3) == 0) {                       // weight fragments of the group three ahead, one load per 4 MFMAs
-          const int u3 = g * 4 + j + 3;            // group index within (this, next) k-tile
-          const int g3 = (u3 >> 2) & 3, j3 = u3 & 3;
+        if constexpr ((mm & 3) == 0) {             // weight fragments of the group three ahead, one load per 4 MFMAs
+          constexpr int u3 = g * 4 + j + 3;        // group index within (this, next) k-tile
+          constexpr int g3 = (u3 >> 2) & 3, j3 = u3 & 3;
           load_b1(u3 >= 16 ? ktn : kt, g3, j3, s_);
           __builtin_amdgcn_sched_barrier(0);
-        } else if ((M & 7) == 2) {                 // Bt d B of patch kt+1 -> V[cur^1]
-          if (M >= 10 && M < 40) {
-            row_piece((M - 10) >> 3);              // M = 10, 18, 26, 34
-            __builtin_amdgcn_sched_barrier(0);
-          } else if (M >= 42 && M < 42 + 128) {
-            col_piece(cur ^ 1, ((M - 42) >> 3) >> 2, ((M - 42) >> 3) & 3);     // M = 42 .. 162
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else if ((M & 7) == 6 && M >= 46 && M < 46 + 128) {
+        } else if constexpr ((M & 7) == 2 && M >= 10 && M < 40) {
+          row_piece((M - 10) >> 3);                // Bt d B of patch kt+1 -> V[cur^1]: M = 10, 18, 26, 34
+          __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr ((M & 7) == 2 && M >= 42 && M < 42 + 128) {
+          col_piece(cur ^ 1, ((M - 42) >> 3) >> 2, ((M - 42) >> 3) & 3);       // M = 42 .. 162
+          __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr ((M & 7) == 6 && M >= 46 && M < 46 + 128) {
           load_patch1(ktnn, (M - 46) >> 3);        // d is free again: patch of k-tile kt+2
           __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (g < 3 && mm == 49) {
+          read_a(ic<g + 1>{});                     // next group's A fragments, a quarter group ahead
+          __builtin_amdgcn_sched_barrier(0);
         }
-        acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[j], s_), comp(bq[j][nb], s_), acc[j][nb], 0, 0, 0);
-      }
+        acc[j][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(a[g & 1][j], s_), comp(bq[j][nb], s_), acc[j][nb], 0, 0, 0);
+      });
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     __syncthreads();
   }
 
