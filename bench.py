@@ -76,7 +76,7 @@ class ConvMeter:
     def __init__(self, K):
         self.K = K
         self.orig = K.conv2d_nhwc
-        self.fam = {k: {"events": [], "algo": 0.0, "exec": 0.0} for k in ("winograd", "direct", "direct_fp16")}
+        self.fam = {k: {"events": [], "algo": 0.0, "exec": 0.0} for k in ("winograd128", "winograd", "direct", "direct_fp16")}
         self.layers = []
 
     def __enter__(self):
@@ -90,7 +90,7 @@ class ConvMeter:
             algo = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin_real
             f = self.fam[self.K.last_conv_path()]
             f["algo"] += algo
-            if self.K.last_conv_path() == "winograd":   # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
+            if self.K.last_conv_path().startswith("winograd"):   # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
                 f["exec"] += 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2) * 16 * cout * cin
             else:
                 f["exec"] += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin
@@ -262,10 +262,11 @@ def main():
         conv_ms = sum(f["ms"] for f in fam.values())
         conv_flops = sum(f["algo_flops"] for f in fam.values())
         n_launch = sum(f["launches"] for f in fam.values())
-        KNAME = {"winograd": "conv3x3_wino_f32 (Winograd F(2x2,3x3), fp32 MFMA)",
+        KNAME = {"winograd128": "conv3x3_wino128_f32 (Winograd F(2x2,3x3), fp32 MFMA, 32 tiles x 128 channels per workgroup)",
+                 "winograd": "conv3x3_wino_f32 (Winograd F(2x2,3x3), fp32 MFMA, 64 tiles x 64 channels per workgroup)",
                  "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
                  "direct_fp16": "conv_igemm_f32<..., HALF> (fp16 MFMA implicit-GEMM conv/linear, fp32 accumulate)"}
-        PKEY = {"winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
+        PKEY = {"winograd128": "conv3x3_wino128_f32", "winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
                 "direct_fp16": "conv_igemm_f16"}
         PEAK = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else FP16_MFMA_PEAK_TFLOPS
         dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time

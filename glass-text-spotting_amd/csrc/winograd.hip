@@ -600,6 +600,8 @@ extern "C" int glass_winograd_supported(const glass_conv_desc* d) {
          d->Ho == d->H && d->Wo == d->W;
 }
 
+extern "C" int glass_winograd_block_channels(int Cout, int Cin) { return wino_wide(Cout, Cin) ? N2 : WN; }
+
 extern "C" size_t glass_winograd_weight_floats(int Cout, int Cin) { return (size_t)16 * (size_t)Cout * (size_t)Cin; }
 
 extern "C" int glass_winograd_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream) {

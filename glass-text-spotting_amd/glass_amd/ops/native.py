@@ -85,7 +85,8 @@ def conv_precision() -> str:
 
 
 def last_conv_path() -> str:
-    """'winograd' or 'direct': which kernel the most recent conv2d_nhwc call launched (bench/profiling aid)."""
+    """'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct' or 'direct_fp16': which kernel
+    the most recent conv2d_nhwc call launched (bench/profiling aid)."""
     return _WINO.get("last_path", "direct")
 
 
@@ -162,7 +163,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
     if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
         u = _winograd_weights(w)
-        _WINO["last_path"] = "winograd"
+        _WINO["last_path"] = "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd"
         check(lib().glass_conv3x3_winograd_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
                                                 c_void_p(_dev(bias, "bias") if bias is not None else None),
                                                 c_void_p(_dev(residual, "residual") if residual is not None else None),

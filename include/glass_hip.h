@@ -81,8 +81,14 @@ int glass_conv2d_nhwc_f16(const glass_conv_desc* d, const float* x, const float*
  *                                          input < 2 GiB), else 0 - callers fall back to glass_conv2d_nhwc.
  *   glass_winograd_weight_floats(Cout,Cin) floats in the packed buffer (16 * Cout * Cin).
  *   glass_winograd_pack_weights            w [Cout][3][3][Cin] (BN-folded) -> U = G w G^t in the kernel's
- *                                          MFMA fragment order; run once per layer at checkpoint load.     */
+ *                                          MFMA fragment order; run once per layer at checkpoint load.
+ *   glass_winograd_block_channels(Cout,Cin) output channels per workgroup of the kernel this layer gets: 128
+ *                                          (conv3x3_wino128_f32: 32 tiles x 128 channels, when Cout % 128 == 0 and
+ *                                          Cin % 32 == 0) or 64 (conv3x3_wino_f32: 64 tiles x 64 channels).  The
+ *                                          packed layout follows the same rule; informational for callers
+ *                                          (profiling / launch-count heuristics).                              */
 int glass_winograd_supported(const glass_conv_desc* d);
+int glass_winograd_block_channels(int Cout, int Cin);
 size_t glass_winograd_weight_floats(int Cout, int Cin);
 int glass_winograd_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream);
 int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,

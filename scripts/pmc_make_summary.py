@@ -11,22 +11,22 @@ import json
 import sys
 
 fetch, write, mfma = (json.load(open(p)) for p in sys.argv[1:4])
-KEYS = {"conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, 1>",
-        "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, 1>",
-        "conv_igemm_f32_128x64": "conv_igemm_f32<2, 2, 2, 1, 1, 4, 32, 1>",
-        "conv_igemm_f32_64x64": "conv_igemm_f32<2, 2, 1, 1, 1, 8, 32, 1>"}
+KEYS = {"conv3x3_wino128_f32": "conv3x3_wino128_f32", "conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, 1",
+        "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, 1",
+        "conv_igemm_f32_128x64": "conv_igemm_f32<2, 2, 2, 1, 1, 4, 32, 1",
+        "conv_igemm_f32_64x64": "conv_igemm_f32<2, 2, 1, 1, 1, 8, 32, 1"}
 
 
 def pick(js, sub, counter):
     for r in js["per_kernel"]:
-        if sub in r["kernel"] and r["counter"] == counter:
+        if sub in r["kernel"] and "true>" not in r["kernel"] and r["counter"] == counter:   # "true>" = the fp16 instantiation
             return r
     return None
 
 
 def ndisp(js, sub):
     for r in js.get("dispatches", []):
-        if sub in r["kernel"]:
+        if sub in r["kernel"] and "true>" not in r["kernel"]:
             return r["n"], r["total_ns"]
     return None, None
 
