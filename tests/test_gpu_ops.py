@@ -42,6 +42,9 @@ WINO_CASES = [
     (1, 64, 64, 128, 128, 1, False, None),
     (5, 8, 32, 512, 256, 0, False, (512, 256)),   # fusion output conv writing into a wider buffer
     (2, 7, 5, 32, 192, 1, True, None),            # three channel blocks, tiny image
+    (1, 5, 5, 32, 128, 2, True, None),            # wide kernel (32 tiles x 128 channels), a single 32-channel k-tile
+    (2, 9, 11, 96, 256, 1, True, None),           # wide kernel, 3 k-tiles, ragged last tile block, odd sizes
+    (1, 31, 40, 64, 384, 0, False, (512, 128)),   # wide kernel, three channel blocks into a wider buffer at an offset
 ]
 
 
@@ -248,6 +251,15 @@ def test_rpn_topk_decode_matches_stable_sort(mode):
         assert torch.equal(os_[:, o:o + k].cpu(), srt), f"level {i}: selected logits / order differ"
         np.testing.assert_allclose(ob[:, o:o + k].cpu().numpy(), boxes.numpy(), rtol=1e-5, atol=1e-4)
         assert (ol[:, o:o + k] == i).all()
+
+
+def test_winograd_block_channels_rule():
+    """which Winograd kernel a layer gets (and therefore which packed-weight layout) is a pure function of (Cout, Cin)"""
+    from glass_amd._lib import lib
+    L = lib()
+    assert L.glass_winograd_block_channels(256, 256) == 128 and L.glass_winograd_block_channels(128, 32) == 128
+    assert L.glass_winograd_block_channels(64, 64) == 64 and L.glass_winograd_block_channels(192, 64) == 64
+    assert L.glass_winograd_block_channels(256, 48) == 64
 
 
 def test_winograd_random_shape_sweep():
