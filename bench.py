@@ -45,7 +45,7 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gc-freeze", type=int, default=1, help="gc.freeze() the warm heap after warmup (0 = off)")
     ap.add_argument("--batch", type=int, default=BATCH)

@@ -30,7 +30,8 @@ for a, b in zip(ends[:-1], ends[1:]):
     if cur_e is not None:
         busy += cur_e - cur_s
     step_lines.append(f"{(b - a) / 1e6:.2f}/{busy / 1e6:.2f}")
-print(f"# rocprofv3 --kernel-trace --stats summary of: python bench.py --steps 5 --warmup 2 --no-cpu-baseline")
+label = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+print(f"# rocprofv3 --kernel-trace --stats summary of: {label}")
 print(f"# source db: {db}; {steps} bench steps in the trace (warmup + timed + 1 metered)")
 print(f"# total kernel time {tot / 1e6:.2f} ms  ({tot / 1e6 / steps:.2f} ms per step)")
 print(f"# per step wall/GPU-busy ms (union of kernel intervals between consecutive postprocess_words ends): {' '.join(step_lines)}")
