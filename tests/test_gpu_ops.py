@@ -253,6 +253,26 @@ def test_rpn_topk_decode_matches_stable_sort(mode):
         assert (ol[:, o:o + k] == i).all()
 
 
+def test_winograd_propagates_non_finite_values_like_the_direct_kernel():
+    """no ReLU: a NaN / inf in the input must come out as NaN / inf (the reference filters non-finite predictions
+    downstream, rotated_fast_rcnn.py:102-107; it never hides them in a conv) - both Winograd kernels and the direct one"""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    for cin, cout in ((32, 128), (16, 64)):
+        x = _rand((1, 8, 8, cin), 5).to(dev)
+        x[0, 3, 3, 0] = float("nan")
+        w = _rand((cout, 3, 3, cin), 6, 0.1).to(dev)
+        for relu in (0, 1):
+            yw = K.conv2d_nhwc(x, w, None, padding=1, relu=relu, winograd=True)
+            yd = K.conv2d_nhwc(x, w, None, padding=1, relu=relu, winograd=False)
+            torch.cuda.synchronize()
+            nan_w, nan_d = torch.isnan(yw), torch.isnan(yd)
+            if relu == 0:
+                assert nan_d[0, 2:5, 2:5, :].all(), "direct kernel lost the NaN"
+                assert nan_w[0, 2:5, 2:5, :].all(), "Winograd kernel lost the NaN"
+            assert not nan_w[0, 6:, 6:, :].any() and not nan_d[0, 6:, 6:, :].any()
+
+
 def test_winograd_block_channels_rule():
     """which Winograd kernel a layer gets (and therefore which packed-weight layout) is a pure function of (Cout, Cin)"""
     from glass_amd._lib import lib
