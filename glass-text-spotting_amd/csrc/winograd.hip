@@ -239,12 +239,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
   // Output role: thread = (4-channel chunk c4, tile ts + 16*pass).  The residual float4s of all 16 output pixels
   // of this thread are requested here, before the LDS exchange, address-selected so that the loads are
   // unconditional and all in flight together (one HBM round trip per block instead of four in series).
+  // 32-bit buffer addressing: a pixel that does not exist (ragged last tile block, odd H / W) gets the out-of-range
+  // offset - its residual load returns zeros and its store is dropped by the hardware; no branches, no 64-bit math.
   const int c4 = tid & 15, ts = tid >> 4;
   const int co = n0 + c4 * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);    // requested now, used after the exchange
   if (p.bias != nullptr) bv = *reinterpret_cast<const float4*>(p.bias + co);
-  long m_base[4];                                 // pixel index of the tile's top-left output, -1: no such tile
-  int oh_ok[4], ow_ok[4];                         // bit a / bit b set: row 2*th+a / column 2*tw+b exists
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_mode == 1 ? p.res : p.y), 0,
+                                                                 (int)(p.res_mode == 1 ? p.r_bytes : 0u), 0x00020000);
+  const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
+  const unsigned rowy = (unsigned)p.W * ldy4, rowr = (unsigned)p.W * ldr4;
+  unsigned yoff[16];                              // [pass][b][a]: byte offset of the output pixel, OOB if it does not exist
   float4 rres[16];
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
@@ -254,19 +260,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
     const int rem = t - n * tpi;
     const int th = fast_div(rem, p.TW, p.magic_tw);
     const int tw = rem - th * p.TW;
-    m_base[pass] = tv ? ((long)n * p.H + 2 * th) * p.W + 2 * tw : -1;
-    oh_ok[pass] = tv ? (1 | ((2 * th + 1 < p.H) ? 2 : 0)) : 0;
-    ow_ok[pass] = tv ? (1 | ((2 * tw + 1 < p.W) ? 2 : 0)) : 0;
-    if (p.res_mode == 1) {
+    const unsigned pix = (unsigned)((n * p.H + 2 * th) * p.W + 2 * tw);
+    const unsigned yb = pix * ldy4 + (unsigned)(p.ycoff + co) * 4u;
+    const unsigned rb = pix * ldr4 + (unsigned)co * 4u;
+    const bool h1 = 2 * th + 1 < p.H, w1 = 2 * tw + 1 < p.W;
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const bool ok = ((oh_ok[pass] >> a) & 1) && ((ow_ok[pass] >> b) & 1);
-          const long m = m_base[pass] + (long)a * p.W + b;
-          rres[pass * 4 + b * 2 + a] = *reinterpret_cast<const float4*>(p.res + (ok ? m * p.ldr + co : 0));
-        }
-    }
+      for (int a = 0; a < 2; ++a) {
+        const bool ok = tv && (a == 0 || h1) && (b == 0 || w1);
+        yoff[pass * 4 + b * 2 + a] = ok ? yb + (a ? rowy : 0u) + (b ? ldy4 : 0u) : OOB;
+        if (p.res_mode == 1)
+          rres[pass * 4 + b * 2 + a] = __builtin_bit_cast(
+              float4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? rb + (a ? rowr : 0u) + (b ? ldr4 : 0u) : OOB, 0, 0));
+      }
   }
   float* zs = smem;
 #pragma unroll
@@ -282,26 +289,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(WinoParams p) {
         zs[((wv * 2 + 1) * WT + row) * ZLD + col] = m1 - m2 - m3;
       }
   __syncthreads();
+  // ReLU before (2) / after (1) the residual add as an unconditional max: max(x, qNaN) = x keeps "no ReLU" exact
+  const float lo2 = p.relu == 2 ? 0.f : __builtin_nanf(""), lo1 = p.relu == 1 ? 0.f : __builtin_nanf("");
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int tile = pass * 16 + ts;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      if (!((ow_ok[pass] >> b) & 1)) continue;
       const float4 z0 = *reinterpret_cast<const float4*>(&zs[((0 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
       const float4 z1 = *reinterpret_cast<const float4*>(&zs[((1 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
       const float4 z2 = *reinterpret_cast<const float4*>(&zs[((2 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
       const float4 z3 = *reinterpret_cast<const float4*>(&zs[((3 * 2 + b) * WT + tile) * ZLD + c4 * 4]);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        if (!((oh_ok[pass] >> a) & 1)) continue;
         float4 v = a == 0 ? add4(add4(z0, z1), z2) : sub4(sub4(z1, z2), z3);
         v = add4(v, bv);
-        if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        const long m = m_base[pass] + (long)a * p.W + b;
+        v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
         if (p.res_mode == 1) v = add4(v, rres[pass * 4 + b * 2 + a]);
-        if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(p.y + m * p.ldy + p.ycoff + co) = v;
+        v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yoff[pass * 4 + b * 2 + a], 0, 0);
       }
     }
   }
