@@ -33,6 +33,7 @@ struct ConvParams {
   int ldx, ldy, ycoff, ycs, relu, res_mode, ldr;
   int M, Ktot, nk, tiles_m, tiles_n, vec_epi;
   unsigned x_bytes, w_bytes;      // buffer sizes for the bounds-checked load paths (0: tensors too large)
+  unsigned y_bytes, r_bytes;      // output / residual spans of the vector epilogue (it is enabled only if they fit 31 bits)
   unsigned magic_cin, magic_kw;   // floor(2^32 / Cin), floor(2^32 / KW) for the per-thread tap decode (MODE 2)
   int half_mode;                  // 1: fp16 operands on v_mfma_f32_32x32x16_f16 (glass_conv2d_nhwc_f16)
 };
@@ -344,31 +345,47 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     // Residual prefetch: a chunk's residual float4s are requested together before its LDS transposition
     // (address-selected, so the loads are unconditional and all in flight) instead of one dependent HBM round
     // trip per output row inside the store loop.
+    // 32-bit buffer addressing (the host enables this path only when the output / residual spans fit 31 bits): a
+    // row or channel group past the edge gets the out-of-range offset - its residual load returns zeros, its store is
+    // dropped by the hardware - so the loops below carry no branches and no 64-bit address arithmetic, and the row
+    // offsets advance by a loop-invariant stride.
+    static_assert(256 % VPR == 0, "a thread keeps its channel group across iterations");
+    constexpr int RPI = 256 / VPR;                 // rows per iteration
+    constexpr unsigned EOOB = 0x7fffffffu;
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_mode != 0 ? p.res : p.y), 0,
+                                                                   (int)(p.res_mode != 0 ? p.r_bytes : 0u), 0x00020000);
+    const int row_t = tid / VPR, c4 = tid - row_t * VPR;
+    const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
+    const float lo2 = p.relu == 2 ? 0.f : __builtin_nanf(""), lo1 = p.relu == 1 ? 0.f : __builtin_nanf("");   // max(x, qNaN) = x
     float4 rres[ITERS];
     auto prefetch_res = [&](int c) {
+      const int co = n0 + c * CW + c4 * 4;
+      const bool cok = co < p.Cout;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
-        const int idx = tid + 256 * it;
-        const int row = idx / VPR, c4 = idx - row * VPR;
-        const int m = m0 + row;
-        const int co = n0 + c * CW + c4 * 4;
-        const bool ok = m < p.M && co < p.Cout;
-        long roff;
+        const int m = m0 + row_t + it * RPI;
+        const bool ok = m < p.M && cok;
+        unsigned roff;
         if (p.res_mode == 1) {
-          roff = (long)m * p.ldr + co;
+          roff = (unsigned)m * ldr4 + (unsigned)co * 4u;
         } else {
           const int n = m / HoWo;
           const int rem = m - n * HoWo;
           const int ho = rem / p.Wo;
           const int wo = rem - ho * p.Wo;
-          roff = ((long)n * HoWo2 + (long)(ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * p.ldr + co;
+          roff = (unsigned)(n * HoWo2 + (ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * ldr4 + (unsigned)co * 4u;
         }
-        rres[it] = *reinterpret_cast<const float4*>(p.res + (ok ? roff : 0));
+        rres[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? roff : EOOB, 0, 0));
       }
     };
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
       if (p.res_mode != 0) prefetch_res(c);        // in flight across the LDS transposition below
+      const int co = n0 + c * CW + c4 * 4;
+      const bool cok = co < p.Cout;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias != nullptr && cok) bv = *reinterpret_cast<const float4*>(p.bias + co);
       __syncthreads();                             // operand reads / previous chunk's read-back done
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -384,26 +401,21 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
         }
       }
       __syncthreads();
+      const unsigned ybase = (unsigned)(m0 + row_t) * ldy4 + (unsigned)(p.ycoff + co) * 4u;
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
-        const int idx = tid + 256 * it;
-        const int row = idx / VPR, c4 = idx - row * VPR;
-        const int m = m0 + row;
-        const int co = n0 + c * CW + c4 * 4;
-        if (m < p.M && co < p.Cout) {
-          float4 v = *reinterpret_cast<const float4*>(&stage[row * SLD + c4 * 4]);
-          if (p.bias != nullptr) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
-            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-          }
-          if (p.relu == 2) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (p.res_mode != 0) {
-            const float4 r = rres[it];
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-          }
-          if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          *reinterpret_cast<float4*>(p.y + (long)m * p.ldy + p.ycoff + co) = v;
+        const int row = row_t + it * RPI;
+        const bool ok = m0 + row < p.M && cok;
+        float4 v = *reinterpret_cast<const float4*>(&stage[row * SLD + c4 * 4]);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
+        if (p.res_mode != 0) {
+          const float4 r = rres[it];
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
+        v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr,
+                                               ok ? ybase + (unsigned)(it * RPI) * ldy4 : EOOB, 0, 0);
       }
     }
     return;
@@ -522,6 +534,14 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   p.vec_epi = (d->y_cstride == 1 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && d->Cout % 4 == 0 &&
                ((uintptr_t)y & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0) &&
                (d->res_mode == 0 || (d->ldr % 4 == 0 && ((uintptr_t)residual & 15) == 0))) ? 1 : 0;
+  {
+    const long yb = M * d->ldy * 4;
+    const long rb = d->res_mode == 1 ? M * d->ldr * 4
+                  : d->res_mode == 2 ? (long)d->N * (d->Ho / 2) * (d->Wo / 2) * d->ldr * 4 : 0;
+    if (yb >= 0x7fffff00L || rb >= 0x7fffff00L) p.vec_epi = 0;      // > 2 GiB output: scalar epilogue (64-bit addresses)
+    p.y_bytes = (unsigned)(p.vec_epi ? yb : 0);
+    p.r_bytes = (unsigned)(p.vec_epi ? rb : 0);
+  }
   hipStream_t s = (hipStream_t)stream;
   static const int force_cfg = getenv("GLASS_CONV_CFG") ? atoi(getenv("GLASS_CONV_CFG")) : 0;   // tuning aid
   if (force_cfg == 1) return launch_conv_impl<2, 2, 2, 2, 1, 3, 32>(p, s);
