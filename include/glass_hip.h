@@ -78,7 +78,9 @@ int glass_conv2d_nhwc_f16(const glass_conv_desc* d, const float* x, const float*
  * error behaviour as glass_conv2d_nhwc; `u_packed` replaces `w`:
  *   glass_winograd_supported(d)            1 if the descriptor can take this path (3x3 s1 p1, Cin % 16 == 0,
  *                                          Cout % 64 == 0, y_cstride == 1, ldy/y_coff % 4 == 0, res_mode 0/1,
- *                                          input < 2 GiB), else 0 - callers fall back to glass_conv2d_nhwc.
+ *                                          input, output and residual spans < 2 GiB each - the kernels use 32-bit
+ *                                          bounds-checked buffer addressing), else 0 - callers fall back to
+ *                                          glass_conv2d_nhwc.
  *   glass_winograd_weight_floats(Cout,Cin) floats in the packed buffer (16 * Cout * Cin).
  *   glass_winograd_pack_weights            w [Cout][3][3][Cin] (BN-folded) -> U = G w G^t in the kernel's
  *                                          MFMA fragment order; run once per layer at checkpoint load.
