@@ -37,7 +37,7 @@ class ReadBack:
                 h = t
             self.host.append(h)
         if any(t.is_cuda for t in self.tensors):
-            self.event = torch.cuda.Event()
+            self.event = torch.cuda.Event(blocking=True)      # let the host thread sleep, not spin, while it waits
             self.event.record()
         return self
 
