@@ -231,10 +231,19 @@ def main():
         gc.collect()
         gc.freeze()
     barrier()
+    prof = None
+    if os.environ.get("GLASS_PROFILE_HOST"):           # diagnostic: cProfile of the timed loop's host side -> stderr
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -221,7 +221,7 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
                           override_boxes: Optional[List[torch.Tensor]] = None):
         """Generator form (utils/pipeline.py): yields a ReadBack where the host needs the detection counts."""
         device = prop_boxes.device
-        hw = torch.tensor(image_sizes, dtype=torch.int32, device=device)
+        hw = K.upload(image_sizes, torch.int32, device)
         ob, os_, oi, orient2, oc = self.box_branch_batched(feats, prop_boxes, prop_counts, hw)
         orient = None
         if orient2 is not None:
@@ -232,16 +232,16 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
             # synthetic-workload hook (bench / teacher-forced parity): recognise these boxes instead
             N = len(override_boxes)
             counts = [len(b) for b in override_boxes]
-            K = max(counts + [1])
-            pb = torch.zeros((N, K, 5), dtype=torch.float32, device=device)
+            kmax = max(counts + [1])
+            pb = torch.zeros((N, kmax, 5), dtype=torch.float32, device=device)
             for n, b in enumerate(override_boxes):
                 if len(b):
                     pb[n, : len(b)] = b.to(device).float()
-            sc = torch.zeros((N, K), dtype=torch.float32, device=device)
+            sc = torch.zeros((N, kmax), dtype=torch.float32, device=device)
             for n, c in enumerate(counts):
                 sc[n, :c] = 1.0
-            det = BatchedDetections(pb, sc, torch.zeros((N, K, 2), device=device) if orient2 is not None else None,
-                                    torch.tensor(counts, dtype=torch.int32, device=device), counts, image_sizes)
+            det = BatchedDetections(pb, sc, torch.zeros((N, kmax, 2), device=device) if orient2 is not None else None,
+                                    K.upload(counts, torch.int32, device), counts, image_sizes)
         return self.recognize_batched(img_nhwc4, feats, det)
 
     def recognize_batched(self, img_nhwc4, feats, det: BatchedDetections) -> BatchedDetections:
@@ -253,7 +253,7 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
             return det          # reference: recognizer_head returns the instances untouched (recognizer_head_v2.py:151)
         device = img_nhwc4.device
         boxes = torch.cat([det.boxes[n, :c] for n, c in enumerate(counts)], 0).contiguous()
-        roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
+        roi_image = K.upload(torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)), torch.int32, device)
         det.text = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts))
         if self.mask_inference:
             det.masks = self.mask_branch_batched(feats, boxes, roi_image)
@@ -266,7 +266,7 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         boxes = roi_image = None
         if R > 0:
             boxes = torch.cat([r.pred_boxes.tensor for r in results], 0).contiguous()
-            roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
+            roi_image = K.upload(torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)), torch.int32, device)
         # reference: with no boxes the recognizer head returns the instances untouched (recognizer_head_v2.py:151)
         if self.recognizer_on and R > 0:
             probs = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts))
@@ -301,8 +301,8 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         pb = torch.zeros((N, P, 5), dtype=torch.float32, device=device)
         for n, p in enumerate(proposals):
             pb[n, : counts[n]] = p.proposal_boxes.tensor
-        hw = torch.tensor([p.image_size for p in proposals], dtype=torch.int32, device=device)
-        cnt = torch.tensor(counts, dtype=torch.int32, device=device)
+        hw = K.upload([p.image_size for p in proposals], torch.int32, device)
+        cnt = K.upload(counts, torch.int32, device)
         ob, os_, oi, orient2, oc = self.box_branch_batched(feats, pb, cnt, hw)
         results, _ = self.box_predictor.to_instances(ob, os_, oi, orient2, oc, [p.image_size for p in proposals])
         return results

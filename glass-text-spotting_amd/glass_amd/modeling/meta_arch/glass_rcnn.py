@@ -107,7 +107,7 @@ class GeneralizedRCNN(InferenceModule):
         images = self.preprocess_image(batched_inputs)
         feats = self.backbone.forward_nhwc(images.nhwc4)
         if detected_instances is None:
-            hw = torch.tensor(images.image_sizes, dtype=torch.int32, device=self._device)
+            hw = K.upload(images.image_sizes, torch.int32, self._device)
             rpn_in = [feats[f] for f in self.proposal_generator.in_features]
             pboxes, _plogits, pcounts = self.proposal_generator.forward_batched(rpn_in, hw)
             det = yield from self.roi_heads.forward_batched_g(images.nhwc4, feats, pboxes, pcounts, images.image_sizes,
@@ -142,9 +142,9 @@ class GeneralizedRCNN(InferenceModule):
             ohw.append([int(height), int(width)])
             out_sizes.append((height, width))
         dev = self._device
-        scale_xy = torch.tensor(sxy, dtype=torch.float32).to(dev)
-        out_hw = torch.tensor(ohw, dtype=torch.int32).to(dev)
-        roi_start = torch.tensor(det.roi_start_host, dtype=torch.int32).to(dev) if (det.text is not None or det.masks is not None) else None
+        scale_xy = K.upload(sxy, torch.float32, dev)
+        out_hw = K.upload(ohw, torch.int32, dev)
+        roi_start = K.upload(det.roi_start_host, torch.int32, dev) if (det.text is not None or det.masks is not None) else None
         ob, os_, oo, ot, oc = K.detections_finalize(det.boxes, det.scores, det.orient, det.text, det.counts_dev, roi_start,
                                                     scale_xy, out_hw, float(self._min_box_dim), self._filter_small)
         om = None

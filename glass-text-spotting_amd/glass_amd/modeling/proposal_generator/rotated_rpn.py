@@ -106,7 +106,7 @@ class RotatedRPN(InferenceModule):
     def forward(self, images: ImageList, features: Dict[str, torch.Tensor], gt_instances=None):
         assert gt_instances is None and not self.training, "inference only"
         feats = [as_nhwc(features[f]) for f in self.in_features]
-        hw = torch.tensor(images.image_sizes, dtype=torch.int32, device=feats[0].device)
+        hw = K.upload(images.image_sizes, torch.int32, feats[0].device)
         boxes, scores, counts = self.forward_batched(feats, hw)
         cnt = counts.cpu().tolist()
         out = []

@@ -10,6 +10,7 @@ from typing import List
 
 import torch
 
+from ...ops import native as K
 from ...utils.module import InferenceModule
 
 from ...structures.core import Instances
@@ -50,8 +51,8 @@ class RecognizerRCNNHeadV3(InferenceModule):
             return instances
         from ..backbone.resnet_fpn import as_nhwc
         counts = [len(i) for i in instances]
-        roi_image = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32),
-                                            torch.tensor(counts)).to(x.device)
+        roi_image = K.upload(torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)),
+                             torch.int32, x.device)
         preds = self.forward_nhwc(as_nhwc(x), roi_image, len(counts))
         for p, inst in zip(preds.split(counts, dim=0), instances):
             inst.pred_text_prob = p

@@ -76,8 +76,8 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
             for dst, src in zip(sc, predictions):
                 dst[n * P: n * P + counts[n]] = src[start: start + counts[n]]
             start += counts[n]
-        hw = torch.tensor([p.image_size for p in proposals], dtype=torch.int32, device=device)
-        cnt = torch.tensor(counts, dtype=torch.int32, device=device)
+        hw = K.upload([p.image_size for p in proposals], torch.int32, device)
+        cnt = K.upload(counts, torch.int32, device)
         ob, os_, oi, orient2, oc = self.inference_batched(tuple(sc) + ((None,) if len(sc) == 2 else ()), pb, cnt, hw)
         return self.to_instances(ob, os_, oi, orient2, oc, [p.image_size for p in proposals])
 

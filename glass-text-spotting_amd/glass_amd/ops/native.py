@@ -48,6 +48,18 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+def upload(data, dtype: torch.dtype, device) -> torch.Tensor:
+    """A few host integers / floats -> device tensor WITHOUT draining the stream.  `torch.tensor(data, device=...)` and
+    `.to(device)` of pageable memory are blocking copies: the host waits for everything queued on the stream before it
+    (the step had ~8 of them = 8 hidden host/GPU synchronisations).  Staged through pinned memory the copy is just one
+    more stream-ordered command (the caching host allocator keeps the staging block alive until the copy has run)."""
+    t = torch.as_tensor(data, dtype=dtype)
+    device = torch.device(device)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def stream_handle() -> int:
     return torch.cuda.current_stream().cuda_stream
 

@@ -188,7 +188,8 @@ class PostProcessorRotatedBoxes:
             pad = torch.zeros((1, K_) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
             pad[0, :n] = t
             extra[name] = pad
-        cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+        from ..ops import native as K
+        cnt = K.upload([n], torch.int32, dev)
         out = self.process_padded(boxes, scores, cnt, text, None, [preds.image_size], extra)[0]
         for name in boxlike:
             out.set(name, RotatedBoxes(out.get(name)))
