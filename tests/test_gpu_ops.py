@@ -356,3 +356,17 @@ def test_conv_fp16_mode_equals_conv_of_fp16_rounded_operands(case):
     got = y.cpu().permute(0, 3, 1, 2).double()
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) <= 1e-5 * scale
+
+
+def test_upload_is_stream_ordered_and_exact():
+    """ops.native.upload (pinned staging, non-blocking copy): the values arrive intact even when the staging tensor is
+    dropped immediately and many uploads are in flight behind a long-running kernel"""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    big = torch.randn((4096, 4096), device=dev)
+    for _ in range(3):
+        big = big @ big * 1e-3                      # keep the stream busy while the uploads are enqueued
+    ups = [K.upload(list(range(i, i + 37)), torch.int32, dev) for i in range(200)]
+    torch.cuda.synchronize()
+    for i, u in enumerate(ups):
+        assert u.tolist() == list(range(i, i + 37))

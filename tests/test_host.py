@@ -250,3 +250,13 @@ def test_host_thread_cap():
         assert limit_host_threads(2) == 1 and torch.get_num_threads() == 2
     finally:
         torch.set_num_threads(before)
+
+
+def test_upload_helper_cpu_semantics():
+    """ops.native.upload: on a CPU device it is a plain typed tensor (the pinned staging only exists for HIP devices)"""
+    import torch
+    from glass_amd.ops import native as K
+    t = K.upload([[3, 4], [5, 6]], torch.int32, "cpu")
+    assert t.dtype == torch.int32 and t.tolist() == [[3, 4], [5, 6]] and t.device.type == "cpu"
+    u = K.upload(torch.tensor([1.5, 2.5]), torch.float32, torch.device("cpu"))
+    assert u.tolist() == [1.5, 2.5]
