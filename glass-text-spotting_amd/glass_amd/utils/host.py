@@ -14,7 +14,7 @@ import os
 
 import torch
 
-DEFAULT_HOST_THREADS = 8
+DEFAULT_HOST_THREADS = 2
 
 
 def usable_cpus() -> int:
@@ -42,7 +42,7 @@ def usable_cpus() -> int:
 
 def limit_host_threads(n: int | None = None) -> int:
     """cap torch's intra-op pool at `n`; returns the previous setting. Default ($GLASS_HOST_THREADS overrides):
-    min(current setting, 8, usable_cpus() / ranks on this node) - it never raises a limit the launcher already set
+    min(current setting, 2, usable_cpus() / ranks on this node) - it never raises a limit the launcher already set
     (torchrun exports OMP_NUM_THREADS=1) and shares the quota between the node's ranks (LOCAL_WORLD_SIZE).
     Call before the first CPU tensor op where possible (the pool is created lazily at that size)."""
     prev = torch.get_num_threads()
