@@ -71,13 +71,17 @@ class ConvMeter:
     """Wraps the conv launches (glass_conv2d_nhwc / glass_conv3x3_winograd_nhwc) with HIP events on the launch
     stream (torch's current stream = the stream every kernel of the path is enqueued on) and tallies, per
     kernel family, the ALGORITHMIC FLOPs (direct-convolution count) and the FLOPs the
-    kernel actually issues to the matrix cores (Winograd F(2x2,3x3): 16 instead of 36 MACs per 2x2 tile)."""
+    kernel actually issues to the matrix cores (Winograd F(2x2,3x3): 16 instead of 36 MACs per 2x2 tile).
+    Several identical steps are metered (`new_step()` between them) and every launch is charged the MEDIAN of its
+    durations over the steps, so that one host hiccup during a metered step cannot distort the per-kernel figures."""
 
     def __init__(self, K):
         self.K = K
         self.orig = K.conv2d_nhwc
-        self.fam = {k: {"events": [], "algo": 0.0, "exec": 0.0} for k in ("winograd128", "winograd", "direct", "direct_fp16")}
-        self.layers = []
+        self.steps = [[]]            # per metered step: [(family, x shape, w dims, stride, +res, algo, exec, e0, e1)]
+
+    def new_step(self):
+        self.steps.append([])
 
     def __enter__(self):
         def wrapped(x, w, bias=None, **kw):
@@ -88,15 +92,13 @@ class ConvMeter:
             cout, kh, kw_, cin = w.shape
             cin_real = 3 if cin == 4 else cin           # NHWC4-padded RGB inputs
             algo = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin_real
-            f = self.fam[self.K.last_conv_path()]
-            f["algo"] += algo
-            if self.K.last_conv_path().startswith("winograd"):   # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
-                f["exec"] += 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2) * 16 * cout * cin
+            path = self.K.last_conv_path()
+            if path.startswith("winograd"):             # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
+                ex = 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2) * 16 * cout * cin
             else:
-                f["exec"] += 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin
-            f["events"].append((e0, e1))
-            self.layers.append((self.K.last_conv_path(), tuple(x.shape), (cout, kh, kw_), kw.get("stride", 1),
-                                kw.get("residual") is not None, algo, e0, e1))
+                ex = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin
+            self.steps[-1].append((path, tuple(x.shape), (cout, kh, kw_), kw.get("stride", 1),
+                                   kw.get("residual") is not None, algo, ex, e0, e1))
             return y
         self.K.conv2d_nhwc = wrapped
         return self
@@ -104,18 +106,33 @@ class ConvMeter:
     def __exit__(self, *a):
         self.K.conv2d_nhwc = self.orig
 
+    def _launches(self):
+        """[(family, x shape, w dims, stride, +res, algo, exec, median ms)] in launch order"""
+        torch.cuda.synchronize()
+        steps = [s for s in self.steps if s]
+        n = len(steps[0])
+        assert all(len(s) == n and [r[:5] for r in s] == [r[:5] for r in steps[0]] for s in steps), \
+            "metered steps must issue the same conv launches"
+        rows = []
+        for i in range(n):
+            ms = sorted(s[i][7].elapsed_time(s[i][8]) for s in steps)
+            rows.append(steps[0][i][:7] + (ms[len(ms) // 2],))
+        return rows
+
     def table(self):
-        """per-launch rows (call after summary()): path, input shape, (Cout, KH, KW), stride, +residual, ms, TFLOP/s"""
-        rows = [(p, xs, ws, st, res, e0.elapsed_time(e1), algo / e0.elapsed_time(e1) / 1e9)
-                for p, xs, ws, st, res, algo, e0, e1 in self.layers]
-        return sorted(rows, key=lambda r: -r[5])
+        """per-launch rows: path, input shape, (Cout, KH, KW), stride, +residual, ms, TFLOP/s (slowest first)"""
+        return sorted(((p, xs, ws, st, res, ms, algo / ms / 1e9) for p, xs, ws, st, res, algo, _ex, ms in self._launches()),
+                      key=lambda r: -r[5])
 
     def summary(self):
-        torch.cuda.synchronize()
-        out = {}
-        for name, f in self.fam.items():
-            ms = sum(a.elapsed_time(b) for a, b in f["events"])
-            out[name] = {"launches": len(f["events"]), "ms": ms, "algo_flops": f["algo"], "exec_flops": f["exec"]}
+        out = {k: {"launches": 0, "ms": 0.0, "algo_flops": 0.0, "exec_flops": 0.0}
+               for k in ("winograd128", "winograd", "direct", "direct_fp16")}
+        for p, _xs, _ws, _st, _res, algo, ex, ms in self._launches():
+            f = out[p]
+            f["launches"] += 1
+            f["ms"] += ms
+            f["algo_flops"] += algo
+            f["exec_flops"] += ex
         return out
 
 
@@ -253,14 +270,17 @@ def main():
 
     line = None
     if rank == 0:
-        # dominant kernel (conv_igemm_f32): one extra instrumented step, outside the timed region
+        # dominant kernel: three extra instrumented steps, outside the timed region
         # (rank-local: must not enter a collective the other ranks are not in)
         # (serial execution: the product overlaps the two halves of the local extractor on two streams,
         #  which would inflate per-kernel event times)
         two = model.roi_heads.two_stream_local
         model.roi_heads.two_stream_local = False
         with ConvMeter(K) as meter:
-            local_step()
+            for rep in range(3):                                  # per-launch median over three identical steps
+                if rep:
+                    meter.new_step()
+                local_step()
             fam = meter.summary()
             if args.conv_table:
                 with open(args.conv_table, "w") as f:
