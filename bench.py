@@ -239,6 +239,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # lazy initialisation, not part of W or K: the first step on each pipeline stream packs the Winograd weights and
+    # fills that stream's allocator pool (hipMalloc); one step per stream so that a small --warmup cannot leave a cold one
+    run_steps(args.pipeline)
     run_steps(args.warmup)
     if args.gc_freeze:
         # serving-loop hygiene, not skipped work: a generation-2 collection walks every object torch created at

@@ -18,6 +18,9 @@ from typing import Callable, Generator, Iterable, List, Optional
 import torch
 
 
+_STREAMS: dict = {}
+
+
 class ReadBack:
     """Request to copy small device tensors to the host.  `start()` enqueues the copies (pinned memory,
     non-blocking) and an event on the current stream; `wait()` blocks on that event and returns the host tensors."""
@@ -74,7 +77,12 @@ def run_pipelined(make_steps: Iterable[Callable[[], Generator]], depth: int = 2,
     # normal-priority streams end up sharing a hardware queue with one of them and the in-flight steps serialise
     # where they should overlap (measured: 200 images/s with both normal vs 210 with the classes alternated or with
     # GPU_MAX_HW_QUEUES=8; 204 unpipelined).  The alternation is about queue placement, not about urgency.
-    streams = [torch.cuda.Stream(device=device, priority=(-1 if i % 2 == 0 else 0)) for i in range(depth)]
+    # The streams are created once per (device, depth): the caching allocator keeps one pool per stream, so fresh
+    # streams on every call would start with cold pools (hipMalloc stalls in the first steps, memory growing per call).
+    key = (str(device), depth)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=device, priority=(-1 if i % 2 == 0 else 0)) for i in range(depth)]
+    streams = _STREAMS[key]
     main = torch.cuda.current_stream(device)
     todo = deque(enumerate(make_steps))
     active = deque()                 # [index, generator, stream, pending ReadBack | None]
