@@ -31,6 +31,8 @@ CONV_CASES = [
     (1, 24, 24, 256, 72, (1, 1), (1, 1), (0, 0), 0, 0),
     (1, 16, 24, 512, 256, (1, 1), (1, 1), (0, 0), 0, 2),
     (2, 8, 32, 512, 256, (3, 3), (1, 1), (1, 1), 0, 0),
+    (3, 7, 9, 64, 40, (1, 1), (1, 1), (0, 0), 2, 0),      # ragged rows and a ragged channel block, ReLU before the residual add
+    (1, 12, 20, 96, 136, (1, 1), (1, 1), (0, 0), 1, 2),   # x2-upsampled residual, 3 channel blocks (last one ragged)
 ]
 
 
