@@ -372,3 +372,26 @@ def test_upload_is_stream_ordered_and_exact():
     torch.cuda.synchronize()
     for i, u in enumerate(ups):
         assert u.tolist() == list(range(i, i + 37))
+
+
+def test_conv_output_larger_than_2gib_takes_the_64bit_epilogue():
+    """the vector epilogue addresses y with 32-bit buffer offsets; an output span >= 2 GiB must fall back to the
+    scalar epilogue with 64-bit addresses (and Winograd must report 'unsupported') - spot-checked against torch CPU"""
+    import ctypes
+    from glass_amd.ops import native as K
+    dev = _dev()
+    N, H, W, Cin, Cout = 1, 1024, 1024, 16, 520           # 1024*1024*520*4 B = 2.03 GiB
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((N, H, W, Cin), generator=g)
+    w = torch.randn((Cout, 1, 1, Cin), generator=g) * 0.2
+    b = torch.randn((Cout,), generator=g)
+    y = K.conv2d_nhwc(x.to(dev), w.to(dev), b.to(dev), relu=1)
+    torch.cuda.synchronize()
+    assert y.numel() * 4 >= 0x7fffff00
+    idx = torch.randint(0, H * W, (512,), generator=g)
+    idx[:4] = torch.tensor([0, 1, H * W - 2, H * W - 1])
+    ref = torch.relu(x.view(-1, Cin)[idx] @ w.view(Cout, Cin).t() + b)
+    got = y.view(-1, Cout)[idx.to(dev)].cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)
+    d = K.ConvDesc(1, 1024, 1024, 64, 576, 3, 3, 1, 1, 1, 1, 1024, 1024, 64, 576, 0, 1, 0, 0, 0)   # y span 2.25 GiB
+    assert K.lib().glass_winograd_supported(ctypes.byref(d)) == 0
