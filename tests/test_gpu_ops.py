@@ -395,3 +395,21 @@ def test_conv_output_larger_than_2gib_takes_the_64bit_epilogue():
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)
     d = K.ConvDesc(1, 1024, 1024, 64, 576, 3, 3, 1, 1, 1, 1, 1024, 1024, 64, 576, 0, 1, 0, 0, 0)   # y span 2.25 GiB
     assert K.lib().glass_winograd_supported(ctypes.byref(d)) == 0
+
+
+def test_conv_input_larger_than_2gib_takes_the_64bit_loads():
+    """the fast load paths use 32-bit buffer offsets; an input span >= 2 GiB must take the generic 64-bit path"""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    H, W, Cin, Cout = 1024, 1024, 520, 16                 # 1024*1024*520*4 B = 2.03 GiB
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((1, H, W, Cin), generator=g)
+    assert x.numel() * 4 >= 0x7fffff00
+    w = torch.randn((Cout, 1, 1, Cin), generator=g) * 0.05
+    b = torch.randn((Cout,), generator=g)
+    y = K.conv2d_nhwc(x.to(dev), w.to(dev), b.to(dev))
+    torch.cuda.synchronize()
+    idx = torch.randint(0, H * W, (512,), generator=g)
+    idx[:4] = torch.tensor([0, 1, H * W - 2, H * W - 1])
+    ref = x.view(-1, Cin)[idx] @ w.view(Cout, Cin).t() + b
+    np.testing.assert_allclose(y.view(-1, Cout)[idx.to(dev)].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)
