@@ -212,12 +212,12 @@ def main():
             model.backbone.forward_nhwc(il.nhwc4)
             return torch.zeros((B, 1), device=dev)
             yield                                                 # pragma: no cover (makes this a generator)
-        yield from model.inference_g(inputs, override_boxes=boxes)   # list[{"instances": Instances}] (views)
-        det = model.last_batch                                    # + the padded device-resident batch
+        out = yield from model.inference_g(inputs, override_boxes=boxes)   # list[{"instances": Instances}] (views)
+        det = out.batch                                           # + this step's padded device-resident batch
         # word post-processing (merge, thresholds, polygons, text decode + text-score filter) for the 8 images
-        yield from post.process_padded_g(det.boxes, det.scores, det.counts_dev, det.text, None, out_sizes,
-                                         {"orientations": det.orient})
-        return pack_words(post.last_words, max_det, steps_txt)    # fixed-size per-image word records
+        words = yield from post.process_padded_g(det.boxes, det.scores, det.counts_dev, det.text, None, out_sizes,
+                                                 {"orientations": det.orient})
+        return pack_words(words.words, max_det, steps_txt)        # fixed-size per-image word records
 
     def step_g():
         rec = yield from local_step_g()

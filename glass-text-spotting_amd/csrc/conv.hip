@@ -506,7 +506,13 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   GLASS_CHECK_ARG(d->Ho == (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1 &&
                       d->Wo == (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1,
                   "glass_conv2d_nhwc: Ho/Wo (%d,%d) inconsistent with input/kernel/stride/pad", d->Ho, d->Wo);
-  GLASS_CHECK_ARG(d->y_cstride >= 1 && d->ldy >= 1, "glass_conv2d_nhwc: bad output strides");
+  GLASS_CHECK_ARG(d->y_cstride >= 1 && d->ldy >= 1 && d->y_coff >= 0, "glass_conv2d_nhwc: bad output strides");
+  // the channel window [y_coff, y_coff + (Cout-1) * y_cstride] must stay inside one pixel's ldy channels: an over-wide
+  // window would silently spill into the next pixel (and be dropped by the bounds check only on the last row)
+  GLASS_CHECK_ARG((long)d->y_coff + (long)(d->Cout - 1) * d->y_cstride < (long)d->ldy,
+                  "glass_conv2d_nhwc: output channel window (y_coff=%d, Cout=%d, y_cstride=%d) exceeds ldy=%d", d->y_coff,
+                  d->Cout, d->y_cstride, d->ldy);
+  GLASS_CHECK_ARG(d->res_mode == 0 || d->ldr >= d->Cout, "glass_conv2d_nhwc: residual ldr=%d < Cout=%d", d->ldr, d->Cout);
   GLASS_CHECK_ARG(d->res_mode == 0 || residual != nullptr, "glass_conv2d_nhwc: res_mode set but residual is null");
   GLASS_CHECK_ARG(d->res_mode != 2 || (d->Ho % 2 == 0 && d->Wo % 2 == 0), "glass_conv2d_nhwc: upsampled residual needs even Ho/Wo");
   GLASS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "glass_conv2d_nhwc: x/w must be 16-byte aligned");

@@ -610,8 +610,9 @@ extern "C" int glass_winograd_supported(const glass_conv_desc* d) {
   const long xb = (long)d->N * d->H * d->W * d->ldx * 4;
   const long yb = (long)d->N * d->H * d->W * d->ldy * 4, rb = d->res_mode == 1 ? (long)d->N * d->H * d->W * d->ldr * 4 : 0;
   return d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 &&
-         d->Cin % WK == 0 && d->Cout % WN == 0 && d->ldx % 4 == 0 && d->y_cstride == 1 && d->ldy % 4 == 0 &&
-         d->y_coff % 4 == 0 && (d->res_mode == 0 || (d->res_mode == 1 && d->ldr % 4 == 0)) && xb < 0x7fffff00L && yb < 0x7fffff00L && rb < 0x7fffff00L &&
+         d->Cin % WK == 0 && d->Cout % WN == 0 && d->ldx % 4 == 0 && d->ldx >= d->Cin && d->y_cstride == 1 && d->ldy % 4 == 0 &&
+         d->y_coff % 4 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->ldy &&
+         (d->res_mode == 0 || (d->res_mode == 1 && d->ldr % 4 == 0 && d->ldr >= d->Cout)) && xb < 0x7fffff00L && yb < 0x7fffff00L && rb < 0x7fffff00L &&
          d->Ho == d->H && d->Wo == d->W;
 }
 

@@ -151,9 +151,32 @@ def unpack_results(rec: torch.Tensor, image_sizes: Sequence[Tuple[int, int]], ma
     return out
 
 
-def all_gather_records(local: torch.Tensor, group=None) -> torch.Tensor:
-    """[n_local, record] on every rank (same n_local) -> [world, n_local, record]; one collective."""
+def shard_rows(num_items: int, world_size: int) -> int:
+    """rows every rank contributes to `all_gather_records` for `num_items` items: the largest shard of
+    `shard_indices` (= ceil(N / W)); smaller shards are padded with count-0 records."""
+    return max(len(shard_indices(num_items, r, world_size)) for r in range(world_size)) if world_size > 0 else 0
+
+
+def gathered_to_global(allrec: torch.Tensor, num_items: int) -> torch.Tensor:
+    """[world, rows, record] from `all_gather_records(..., rows=shard_rows(N, W))` -> [N, record] in global item order
+    (drops the padding rows of the short shards)."""
+    world = allrec.shape[0]
+    parts = [allrec[r, :len(shard_indices(num_items, r, world))] for r in range(world)]
+    return torch.cat(parts, 0) if parts else allrec.reshape(0, allrec.shape[-1])
+
+
+def all_gather_records(local: torch.Tensor, group=None, rows: int = None) -> torch.Tensor:
+    """[n_local, record] on every rank -> [world, rows, record]; one collective.  `all_gather_into_tensor` needs the
+    same row count on every rank: with `rows` (= `shard_rows(N, W)`) a short shard is padded with all-zero records
+    (count 0); without it every rank must pass the same n_local (N % W == 0) - anything else raises here instead of
+    hanging or mis-viewing inside the collective."""
     import torch.distributed as dist
+    if rows is not None:
+        if local.shape[0] > rows:
+            raise ValueError(f"all_gather_records: {local.shape[0]} local records > rows={rows}")
+        if local.shape[0] < rows:
+            pad = torch.zeros((rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            local = torch.cat([local, pad], 0)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local.unsqueeze(0)
     world = dist.get_world_size(group)

@@ -90,9 +90,9 @@ class GlassRunner:
         out = [None] * len(inputs)
         for idxs in groups.values():
             raw = self.model([inputs[i] for i in idxs])
-            if self.post_process_flag and self.model.last_batch is not None:
+            det = getattr(raw, "batch", None)          # this call's padded device-resident batch (pipeline.StepOutput)
+            if self.post_process_flag and det is not None:
                 # un-scale + the whole word post-processing for the group in one kernel (no per-image host loop)
-                det = self.model.last_batch
                 if det.text is None and sum(det.counts_host) > 0:
                     raise RuntimeError("recognizer output missing")
                 sc = torch.tensor([[1.0 / ratios[i], 1.0 / ratios[i]] for i in idxs], dtype=torch.float32).to(self.device)

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from ...utils.module import InferenceModule
-from ...utils.pipeline import ReadBack, drive
+from ...utils.pipeline import ReadBack, StepOutput, drive, segment_scoped
 
 from ...checkpoint import load_checkpoint_file
 from ...ops import native as K
@@ -46,7 +46,9 @@ class GeneralizedRCNN(InferenceModule):
         self.input_format = cfg.INPUT.FORMAT
         self.conv_precision = str(cfg.MODEL.CONV_PRECISION) if hasattr(cfg.MODEL, "CONV_PRECISION") else "fp32"
         self._loaded = False
-        self.last_batch = None      # padded device-resident results of the last step (for distributed.pack_padded)
+        # padded device-resident results of the most recent synchronous call.  With several steps in flight
+        # (utils.pipeline.run_pipelined) read `.batch` of the step's own return value (pipeline.StepOutput) instead.
+        self.last_batch = None
 
     @property
     def device(self) -> torch.device:
@@ -97,11 +99,11 @@ class GeneralizedRCNN(InferenceModule):
         assert not self.training
         if not self._loaded:
             raise RuntimeError("no weights loaded: call load_state_dict()/load_checkpoint() first")
-        prev_precision = K.set_conv_precision(self.conv_precision)
-        try:
-            return (yield from self._inference_body_g(batched_inputs, detected_instances, do_postprocess, override_boxes))
-        finally:
-            K.set_conv_precision(prev_precision)
+        # the conv precision is process-global state in ops.native: switch it per SEGMENT, never across a yield (the
+        # other in-flight steps of run_pipelined run between this generator's segments)
+        return (yield from segment_scoped(
+            self._inference_body_g(batched_inputs, detected_instances, do_postprocess, override_boxes),
+            lambda: K.set_conv_precision(self.conv_precision), K.set_conv_precision))
 
     def _inference_body_g(self, batched_inputs, detected_instances, do_postprocess, override_boxes):
         images = self.preprocess_image(batched_inputs)
@@ -114,8 +116,10 @@ class GeneralizedRCNN(InferenceModule):
                                                               override_boxes=override_boxes)
             if do_postprocess:
                 return (yield from self._postprocess_batched_g(det, batched_inputs, images.image_sizes))
-            self.last_batch = det
-            return det.to_instances()
+            self.last_batch = det                # convenience for the synchronous API only; pipelined callers use .batch
+            out = StepOutput(det.to_instances())
+            out.batch = det
+            return out
         detected_instances = [x.to(self._device) for x in detected_instances]
         results = self.roi_heads._recognize_into(images.nhwc4, feats, detected_instances)
         if do_postprocess:
@@ -168,10 +172,12 @@ class GeneralizedRCNN(InferenceModule):
                     rb.scale(sxy[n][0], sxy[n][1])
                     rb.clip(out_sizes[n])
                 r.pred_rboxes = rb
-        return [{"instances": r} for r in results]
+        out = StepOutput({"instances": r} for r in results)
+        out.batch = post
+        return out
 
     def _postprocess(self, instances, batched_inputs, image_sizes):
-        out = []
+        out = StepOutput()
         for r, inp, image_size in zip(instances, batched_inputs, image_sizes):
             height = inp.get("height", image_size[0])
             width = inp.get("width", image_size[1])

@@ -157,6 +157,13 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         _f32c(out, "out")
         if tuple(out.shape[:3]) != (N, Ho, Wo):
             raise GlassLibraryError(f"out has shape {tuple(out.shape)}, expected ({N},{Ho},{Wo},*)")
+    if out_coff < 0 or out_cstride < 1 or out_coff + (Cout - 1) * out_cstride >= out.shape[3]:
+        raise GlassLibraryError(f"output channel window (offset {out_coff}, {Cout} channels, stride {out_cstride}) does not "
+                                f"fit the {out.shape[3]} channels of out")
+    if residual is not None and residual.shape[-1] < Cout:
+        raise GlassLibraryError(f"residual has {residual.shape[-1]} channels, conv produces {Cout}")
+    if ldx < Cin:
+        raise GlassLibraryError(f"x has {ldx} channels, weight expects {Cin}")
     d = ConvDesc(N, H, W, Cin, Cout, KH, KW, sh, sw, ph, pw, Ho, Wo, ldx, out.shape[3], out_coff, out_cstride, relu,
                  res_mode if residual is not None else 0, residual.shape[-1] if residual is not None else 0)
     if residual is not None:

@@ -121,14 +121,14 @@ class PostProcessorRotatedBoxes:
         use_text = text is not None and self.text_threshold is not None
         stop = self.text_encoder.character.index("[s]") if use_text else 1
         out = K.postprocess_words(boxes, scores, counts_dev, text if use_text else None, scale_xy, self._thresholds(), stop)
-        self.last_words = out              # padded device tensors of this call (distributed.pack_words)
-        from ..utils.pipeline import ReadBack
+        from ..utils.pipeline import ReadBack, StepOutput
         if use_text:          # one read-back (generator form: utils/pipeline.py) of counts, characters and lengths
             h_count, h_char, h_len = yield ReadBack(out["count"], out["char"], out["text_len"])
             counts, chars, tlen = h_count.tolist(), h_char.numpy(), h_len.tolist()
         else:
             counts, chars, tlen = (yield ReadBack(out["count"]))[0].tolist(), None, None
-        results = []
+        results = StepOutput()
+        results.words = out                # padded device tensors of THIS call (distributed.pack_words)
         for n, size in enumerate(image_sizes):
             c = counts[n]
             r = Instances(tuple(size))

@@ -12,6 +12,7 @@ read-back, step k+1's kernels are already queued, and k's tail overlaps k+1's ba
 """
 from __future__ import annotations
 
+import contextlib
 from collections import deque
 from typing import Callable, Generator, Iterable, List, Optional
 
@@ -50,6 +51,63 @@ class ReadBack:
         return self.host
 
 
+class StepOutput(list):
+    """The list a step generator returns (`list[{'instances': Instances}]` / `list[Instances]`, the reference's return
+    types) carrying that step's padded device-resident tensors as attributes (`.batch`: BatchedDetections of the
+    meta-arch, `.words`: the word post-processor's padded outputs).  Per-step state travels WITH the result: with
+    several steps in flight a `model.last_*` attribute is overwritten by whichever step ran last."""
+    batch = None
+    words = None
+
+
+def segment_scoped(gen: Generator, enter: Callable, leave: Callable):
+    """Run `gen` with `tok = enter()` ... `leave(tok)` around EVERY segment (the code between two yields) instead of
+    around the whole generator: process-global settings (conv precision) must not stay switched while the other
+    in-flight steps of `run_pipelined` execute their segments."""
+    val, first = None, True
+    while True:
+        tok = enter()
+        try:
+            req = next(gen) if first else gen.send(val)
+        except StopIteration as e:
+            return e.value
+        finally:
+            leave(tok)
+        first = False
+        val = yield req
+
+
+def _record_stream(obj, stream, depth: int = 0) -> None:
+    """caching-allocator hygiene for results that leave their producing stream: the blocks were allocated from the
+    side stream's pool and are consumed on `stream`; without record_stream they could be recycled by the next step on
+    the side stream while kernels queued on `stream` still read them."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream, depth + 1)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream, depth + 1)
+        for name in ("batch", "words"):
+            if getattr(obj, name, None) is not None:
+                _record_stream(getattr(obj, name), stream, depth + 1)
+    elif depth < 6 and hasattr(obj, "__dict__"):
+        for v in vars(obj).values():
+            _record_stream(v, stream, depth + 1)
+
+
+class _HostStream:
+    """stand-in for a HIP stream when the schedule runs on host tensors only"""
+    def wait_stream(self, other) -> None:
+        pass
+
+
+def _on(stream):
+    return contextlib.nullcontext() if isinstance(stream, _HostStream) else torch.cuda.stream(stream)
+
+
 def drive(gen: Generator):
     """Run a step generator to completion, serving each read-back immediately (the synchronous API)."""
     # grad mode is thread-global state: it is set around every segment here (a `with torch.no_grad()` that spans a
@@ -79,24 +137,31 @@ def run_pipelined(make_steps: Iterable[Callable[[], Generator]], depth: int = 2,
     # GPU_MAX_HW_QUEUES=8; 204 unpipelined).  The alternation is about queue placement, not about urgency.
     # The streams are created once per (device, depth): the caching allocator keeps one pool per stream, so fresh
     # streams on every call would start with cold pools (hipMalloc stalls in the first steps, memory growing per call).
+    on_gpu = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
     key = (str(device), depth)
-    if key not in _STREAMS:
-        _STREAMS[key] = [torch.cuda.Stream(device=device, priority=(-1 if i % 2 == 0 else 0)) for i in range(depth)]
-    streams = _STREAMS[key]
-    main = torch.cuda.current_stream(device)
+    if not on_gpu:
+        # host-only use (the gloo tests of the step schedule): same interleaving, no streams
+        streams, main = [_HostStream() for _ in range(depth)], _HostStream()
+    else:
+        if key not in _STREAMS:
+            _STREAMS[key] = [torch.cuda.Stream(device=device, priority=(-1 if i % 2 == 0 else 0)) for i in range(depth)]
+        streams = _STREAMS[key]
+        main = torch.cuda.current_stream(device)
     todo = deque(enumerate(make_steps))
     active = deque()                 # [index, generator, stream, pending ReadBack | None]
     results = {}
 
     def advance(slot) -> bool:
         idx, gen, st, req = slot
-        with torch.cuda.stream(st), torch.no_grad():
+        with _on(st), torch.no_grad():
             try:
                 nxt = next(gen) if req is None else gen.send(req.wait())
                 slot[3] = nxt.start()
                 return True
             except StopIteration as e:
                 results[idx] = e.value
+                if not isinstance(main, _HostStream):
+                    _record_stream(e.value, main)
                 return False
 
     while todo or active:
@@ -105,7 +170,7 @@ def run_pipelined(make_steps: Iterable[Callable[[], Generator]], depth: int = 2,
             st = streams[idx % depth]
             st.wait_stream(main)                      # inputs prepared on the caller's stream
             slot = [idx, None, st, None]
-            with torch.cuda.stream(st):
+            with _on(st):
                 slot[1] = mk()
             if advance(slot):
                 active.append(slot)

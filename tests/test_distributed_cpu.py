@@ -54,3 +54,120 @@ def test_two_rank_shard_and_gather():
     got.sort()
     assert got[0][1] == [0, 1, 2] and got[1][1] == [3, 4, 5]
     assert all(g[2] for g in got)
+
+
+def _fake_words(rank, step, n_images, D, T):
+    """deterministic padded word-post-processor outputs of (rank, step): every field encodes its owner"""
+    K = D
+    tag = 100.0 * step + 10.0 * rank
+    count = torch.tensor([(i + rank + step) % (D + 1) for i in range(n_images)], dtype=torch.int32)
+    return {"count": count,
+            "boxes": torch.full((n_images, K, 5), tag) + torch.arange(n_images).view(-1, 1, 1),
+            "scores": torch.full((n_images, K), tag + 0.5),
+            "text_score": torch.full((n_images, K), tag + 0.25),
+            "polygons": torch.full((n_images, K, 4, 2), tag + 1.0),
+            "text_len": torch.full((n_images, K), (step % 3) + 1, dtype=torch.int32),
+            "char": torch.full((n_images, K, T), 3 + (step + rank) % 5, dtype=torch.int32)}
+
+
+def _pipelined_worker(rank, world, port, q):
+    """the bench step's host schedule (bench.py step_g) with two steps in flight: three read-back yields, pack_words,
+    ONE all_gather of the ragged shards; the step's own outputs must come back from every rank, in step order."""
+    sys.path.insert(0, os.path.join(ROOT, "glass-text-spotting_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from glass_amd.distributed import (all_gather_records, gathered_to_global, pack_words, shard_indices, shard_rows,
+                                       unpack_words, words_record_size)
+    from glass_amd.utils.pipeline import ReadBack, StepOutput, run_pipelined
+    N_GLOBAL, D, T, STEPS = 7, 4, 6, 5                     # 7 images over 2 ranks: shards of 3 and 4 (ragged)
+    mine = shard_indices(N_GLOBAL, rank, world)
+    rows = shard_rows(N_GLOBAL, world)
+    chars = [chr(ord("a") + i) for i in range(26)]
+    order = []
+
+    def make(step):
+        def gen():
+            words = _fake_words(rank, step, len(mine), D, T)
+            h = yield ReadBack(words["count"])                 # detection counts
+            assert h[0].tolist() == words["count"].tolist()
+            yield ReadBack(words["count"])                     # surviving counts
+            out = StepOutput()
+            out.words = words
+            yield ReadBack(words["count"], words["char"], words["text_len"])   # word post-processor
+            order.append(step)
+            rec = pack_words(out.words, D, T)
+            assert rec.shape == (len(mine), words_record_size(D, T))
+            return step, all_gather_records(rec, rows=rows)
+        return gen
+
+    res = run_pipelined([make(s) for s in range(STEPS)], depth=2, device="cpu")
+    ok = [s for s, _ in res] == list(range(STEPS)) and order == list(range(STEPS))
+    for step, allrec in res:
+        ok &= tuple(allrec.shape[:2]) == (world, rows)
+        glob = gathered_to_global(allrec, N_GLOBAL)
+        ok &= glob.shape[0] == N_GLOBAL
+        back = unpack_words(glob, D, T, chars)
+        for g, b in enumerate(back):
+            r = 0 if g in shard_indices(N_GLOBAL, 0, world) else 1
+            i = g - shard_indices(N_GLOBAL, r, world)[0]
+            k = (i + r + step) % (D + 1)
+            tag = 100.0 * step + 10.0 * r
+            ok &= len(b["texts"]) == k
+            if k:
+                ok &= float(b["boxes"][0, 0]) == tag + i and abs(float(b["scores"][0]) - (tag + 0.5)) < 1e-6
+                ok &= b["texts"][0] == chars[3 + (step + r) % 5] * ((step % 3) + 1)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_steps_ragged_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got == [(0, True), (1, True)]
+
+
+def test_gather_rejects_oversized_shard_and_pads_single_rank():
+    sys.path.insert(0, os.path.join(ROOT, "glass-text-spotting_amd"))
+    import pytest
+    from glass_amd.distributed import all_gather_records, gathered_to_global, shard_rows
+    assert shard_rows(7, 2) == 4 and shard_rows(8, 8) == 1 and shard_rows(3, 8) == 1
+    rec = torch.arange(6.0).view(3, 2)
+    out = all_gather_records(rec, rows=4)                   # no process group: world 1
+    assert out.shape == (1, 4, 2) and float(out[0, 3].abs().sum()) == 0.0
+    assert torch.equal(gathered_to_global(out, 3), rec)
+    with pytest.raises(ValueError):
+        all_gather_records(rec, rows=2)
+
+
+def test_segment_scoped_restores_between_segments():
+    """process-global settings (conv precision) are switched per segment, never across a yield."""
+    sys.path.insert(0, os.path.join(ROOT, "glass-text-spotting_amd"))
+    from glass_amd.utils.pipeline import ReadBack, run_pipelined, segment_scoped
+    state = {"v": "fp32"}
+    seen = []
+
+    def setv(v):
+        prev, state["v"] = state["v"], v
+        return prev
+
+    def body(name, want):
+        for seg in range(3):
+            seen.append((name, seg, state["v"]))
+            assert state["v"] == want
+            yield ReadBack(torch.zeros(1))
+        return name
+
+    def mk(name, want):
+        return lambda: segment_scoped(body(name, want), lambda: setv(want), setv)
+
+    res = run_pipelined([mk("a", "fp16"), mk("b", "fp32"), mk("c", "fp16")], depth=2, device="cpu")
+    assert res == ["a", "b", "c"] and state["v"] == "fp32" and len(seen) == 9
