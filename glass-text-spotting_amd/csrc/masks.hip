@@ -47,7 +47,19 @@ struct PasteParams {
   float threshold;
 };
 
-// one thread per 4 consecutive output pixels of one RoI row (32-bit packed store)
+// one thread per 4 consecutive output pixels of one RoI row (32-bit packed store).
+// BIT-EXACT against the reference's torch-CPU path (tests/golden/mask_paste.npz, produced by the reference's own
+// paste_masks_in_image): every fp32 operation below is the one torch executes, in its order, with fusion exactly where
+// torch's kernels fuse (established by emulation, oracle/README notes + tests/test_mask_branch.py):
+//   * `stack([gx, gy]) @ rot` is an sgemm with K = 2: acc = gx * r0; acc = fma(gy, r1, acc);
+//   * the following `+= c`, `- x0`, `/ (x1 - x0)`, `* 2`, `- 1` are separate elementwise kernels (each rounded);
+//   * grid_sample (CPU, vectorised): unnormalise = fma(n + 1, M / 2, -0.5); weights e = 1 - w, s = 1 - n,
+//     nw = e*s, ne = w*s, sw = e*n, se = w*n; out = nw_v*nw, then fma(ne_v, ne, out), fma(sw_v, sw, out), fma(se_v, se, out)
+//     with out-of-range taps contributing a value of 0 (masked gather);
+//   * cos / sin: correctly rounded fp32 (evaluated in fp64 and rounded), which is what torch's SLEEF kernels return
+//     for all but rare inputs.
+// Compiler contraction is off for this kernel; the fused operations are explicit __builtin_fmaf calls.
+#pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void paste_rotated_masks_kernel(PasteParams p) {
   const int r = blockIdx.z;
   const int py = blockIdx.y;
@@ -55,9 +67,13 @@ __global__ __launch_bounds__(256) void paste_rotated_masks_kernel(PasteParams p)
   const float cx = b[0], cy = b[1], bw = b[2], bh = b[3];
   // torch.deg2rad multiplies by pi/180 in fp32
   const float ang = b[4] * 0.017453292519943295f;
-  const float cs = cosf(ang), sn = sinf(ang);
-  const float x0 = cx + (0.f - bw) / 2, x1 = cx - (0.f - bw) / 2;      // sin_t = 0, cos_t = 1 in the reference
-  const float y0 = cy - (bh + 0.f) / 2, y1 = cy + (bh + 0.f) / 2;
+  const float cs = (float)cos((double)ang), sn = (float)sin((double)ang);
+  const float nsn = -sn;
+  // x0 = cx + (h * sin_t - w * cos_t) / 2 with sin_t = 0, cos_t = 1 (python ints in the reference)
+  const float x0 = cx + (bh * 0.f - bw * 1.f) / 2.f, x1 = cx - (bh * 0.f - bw * 1.f) / 2.f;
+  const float y0 = cy - (bh * 1.f + bw * 0.f) / 2.f, y1 = cy + (bh * 1.f + bw * 0.f) / 2.f;
+  const float dx = x1 - x0, dy = y1 - y0;
+  const float halfM = (float)p.M / 2.f;
   const float* mk = p.masks + (long)r * p.M * p.M;
   uint8_t* orow = p.out + ((long)r * p.H + py) * p.W;
   const float gy = ((float)py + 0.5f) - cy;
@@ -69,31 +85,40 @@ __global__ __launch_bounds__(256) void paste_rotated_masks_kernel(PasteParams p)
       uint32_t bit = 0;
       if (px < p.W) {
         const float gx = ((float)px + 0.5f) - cx;
-        // [gx, gy] @ [[cos, sin], [-sin, cos]], recentred, normalised to the box
-        float ix = gx * cs + gy * (-sn);
-        float iy = gx * sn + gy * cs;
-        ix += cx;
-        iy += cy;
-        const float nx = (ix - x0) / (x1 - x0) * 2.f - 1.f;
-        const float ny = (iy - y0) / (y1 - y0) * 2.f - 1.f;
-        // grid_sample, align_corners=False: pixel = ((n + 1) * size - 1) / 2, bilinear, zeros outside
-        const float fx = ((nx + 1.f) * (float)p.M - 1.f) * 0.5f;
-        const float fy = ((ny + 1.f) * (float)p.M - 1.f) * 0.5f;
+        // [gx, gy] @ [[cos, sin], [-sin, cos]] (K = 2 sgemm), recentred, normalised to the box
+        float ix = __builtin_fmaf(gy, nsn, gx * cs);
+        float iy = __builtin_fmaf(gy, cs, gx * sn);
+        ix = ix + cx;
+        iy = iy + cy;
+        float nx = (ix - x0) / dx;
+        nx = nx * 2.f;
+        nx = nx - 1.f;
+        float ny = (iy - y0) / dy;
+        ny = ny * 2.f;
+        ny = ny - 1.f;
+        // grid_sample, align_corners=False, bilinear, zero padding
+        const float fx = __builtin_fmaf(nx + 1.f, halfM, -0.5f);
+        const float fy = __builtin_fmaf(ny + 1.f, halfM, -0.5f);
         const float flx = floorf(fx), fly = floorf(fy);
-        const int xw = (int)flx, yn = (int)fly;
-        const float tx = fx - flx, ty = fy - fly;
         float v = 0.f;
-        // torch's CPU kernel accumulates nw, ne, sw, se in this order
-        const bool xin0 = xw >= 0 && xw < p.M, xin1 = xw + 1 >= 0 && xw + 1 < p.M;
-        const bool yin0 = yn >= 0 && yn < p.M, yin1 = yn + 1 >= 0 && yn + 1 < p.M;
-        if (fx > -2.f && fx < (float)p.M + 1.f && fy > -2.f && fy < (float)p.M + 1.f) {
-          if (yin0 && xin0) v += mk[yn * p.M + xw] * ((1.f - tx) * (1.f - ty));
-          if (yin0 && xin1) v += mk[yn * p.M + xw + 1] * (tx * (1.f - ty));
-          if (yin1 && xin0) v += mk[(yn + 1) * p.M + xw] * ((1.f - tx) * ty);
-          if (yin1 && xin1) v += mk[(yn + 1) * p.M + xw + 1] * (tx * ty);
+        if (flx >= -1.f && flx < (float)p.M && fly >= -1.f && fly < (float)p.M) {   // (also false for NaN: v stays 0)
+          const int xw = (int)flx, yn = (int)fly;
+          const float tw = fx - flx, te = 1.f - tw, tn = fy - fly, ts = 1.f - tn;
+          const float wnw = te * ts, wne = tw * ts, wsw = te * tn, wse = tw * tn;
+          const bool xin0 = xw >= 0, xin1 = xw + 1 < p.M;
+          const bool yin0 = yn >= 0, yin1 = yn + 1 < p.M;
+          const float vnw = (yin0 && xin0) ? mk[yn * p.M + xw] : 0.f;
+          const float vne = (yin0 && xin1) ? mk[yn * p.M + xw + 1] : 0.f;
+          const float vsw = (yin1 && xin0) ? mk[(yn + 1) * p.M + xw] : 0.f;
+          const float vse = (yin1 && xin1) ? mk[(yn + 1) * p.M + xw + 1] : 0.f;
+          v = vnw * wnw;
+          v = __builtin_fmaf(vne, wne, v);
+          v = __builtin_fmaf(vsw, wsw, v);
+          v = __builtin_fmaf(vse, wse, v);
         }
         // threshold >= 0: boolean mask; threshold < 0: the reference's visualisation mode, (v * 255).to(uint8)
-        bit = p.threshold >= 0.f ? ((v >= p.threshold) ? 1u : 0u) : ((uint32_t)(int)(v * 255.f) & 0xffu);
+        const float v255 = v * 255.f;
+        bit = p.threshold >= 0.f ? ((v >= p.threshold) ? 1u : 0u) : ((uint32_t)(int)v255 & 0xffu);
       }
       packed |= bit << (8 * k);
     }

@@ -44,6 +44,9 @@ class BatchedDetections:
         self.counts_dev, self.counts_host, self.image_sizes = counts_dev, list(counts_host), list(image_sizes)
         self.text = None
         self.masks = None             # [sum counts, 1, M, M] mask probabilities (MASK_INFERENCE), or padded [N,K,M,M]
+        self.kept_index = None        # [N,K] int32: index into the image's proposal list each detection came from
+        self.detected = None          # with override_boxes: the box head's own detections (this object holds the overrides)
+        self.proposals = None         # (boxes [N,P,5], logits [N,P], counts [N]) of the RPN, set by the meta-arch
         self.roi_start_host = [0]
         for c in self.counts_host[:-1]:
             self.roi_start_host.append(self.roi_start_host[-1] + c)
@@ -228,7 +231,9 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
             orient = torch.gather(orient2, 1, oi.long().unsqueeze(-1).expand(-1, -1, 2))
         counts = (yield ReadBack(oc))[0].tolist()     # host read-back: per-image detection counts size the recognizer batch
         det = BatchedDetections(ob, os_, orient, oc, counts, image_sizes)
+        det.kept_index = oi
         if override_boxes is not None:
+            real = det
             # synthetic-workload hook (bench / teacher-forced parity): recognise these boxes instead
             N = len(override_boxes)
             counts = [len(b) for b in override_boxes]
@@ -242,6 +247,7 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
                 sc[n, :c] = 1.0
             det = BatchedDetections(pb, sc, torch.zeros((N, kmax, 2), device=device) if orient2 is not None else None,
                                     K.upload(counts, torch.int32, device), counts, image_sizes)
+            det.detected = real
         return self.recognize_batched(img_nhwc4, feats, det)
 
     def recognize_batched(self, img_nhwc4, feats, det: BatchedDetections) -> BatchedDetections:

@@ -114,6 +114,7 @@ class GeneralizedRCNN(InferenceModule):
             pboxes, _plogits, pcounts = self.proposal_generator.forward_batched(rpn_in, hw)
             det = yield from self.roi_heads.forward_batched_g(images.nhwc4, feats, pboxes, pcounts, images.image_sizes,
                                                               override_boxes=override_boxes)
+            det.proposals = (pboxes, _plogits, pcounts)      # padded RPN output of this step (parity tests, debugging)
             if do_postprocess:
                 return (yield from self._postprocess_batched_g(det, batched_inputs, images.image_sizes))
             self.last_batch = det                # convenience for the synchronous API only; pipelined callers use .batch

@@ -47,6 +47,14 @@ static void rotated_vertices(const rbox* box, pt pts[4]) {
   pts[3].y = 2 * box->y_ctr - pts[1].y;
 }
 
+/* exported for the direction-pinning tests: the 4 vertices of (cx, cy, w, h, angle_deg) in d2's order */
+void d2o_rotated_vertices(const float* r, float* out8) {
+  rbox b = {r[0], r[1], r[2], r[3], r[4]};
+  pt p[4];
+  rotated_vertices(&b, p);
+  for (int i = 0; i < 4; i++) { out8[2 * i] = p[i].x; out8[2 * i + 1] = p[i].y; }
+}
+
 static int intersection_points(const pt p1[4], const pt p2[4], pt out[24]) {
   pt v1[4], v2[4];
   for (int i = 0; i < 4; i++) {

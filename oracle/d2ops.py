@@ -49,6 +49,7 @@ def lib():
         fp = ctypes.POINTER(ctypes.c_float)
         L.d2o_single_box_iou_rotated.restype = ctypes.c_float
         L.d2o_single_box_iou_rotated.argtypes = [fp, fp]
+        L.d2o_rotated_vertices.argtypes = [fp, fp]
         L.d2o_pairwise_iou_rotated.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, fp]
         L.d2o_nms_rotated.restype = ctypes.c_int
         L.d2o_nms_rotated.argtypes = [fp, fp, ctypes.c_int, ctypes.c_float,
@@ -70,6 +71,14 @@ def _p(a: np.ndarray):
 
 
 # ---------------------------------------------------------------- native wrappers
+def rotated_vertices(box) -> np.ndarray:
+    """(cx, cy, w, h, angle_deg) -> [4, 2] vertices in d2's order (box_iou_rotated_utils.h get_rotated_vertices)"""
+    b = _f32(box).reshape(5)
+    out = np.zeros((8,), dtype=np.float32)
+    lib().d2o_rotated_vertices(_p(b), _p(out))
+    return out.reshape(4, 2)
+
+
 def pairwise_iou_rotated(b1, b2) -> torch.Tensor:
     a, b = _f32(b1).reshape(-1, 5), _f32(b2).reshape(-1, 5)
     out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity import TOL, assert_detections_close, assert_same_box_set as _assert_same_box_set, assert_text_prob_close, maxdiff
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -24,6 +26,29 @@ def sd():
     return make_state_dict(1234)
 
 
+def _compare_proposals(det, n, ref_props, what):
+    """RPN output of image n (padded device tensors on det.proposals) vs the oracle's (boxes, logits)"""
+    pb, pl, pc = det.proposals
+    c = int(pc[n])
+    rb, rs = ref_props
+    assert c == len(rb), f"{what}: {c} proposals vs oracle {len(rb)}"
+    d = maxdiff(pl[n, :c].cpu().numpy(), rs.numpy())
+    print(f"[parity] {what}: {c} proposals, max |dlogit| = {d:.3e}")
+    assert d < TOL
+    _assert_same_box_set(pb[n, :c].cpu().numpy(), rb.numpy())
+
+
+def _compare_detections(det, n, ref, what):
+    c = det.counts_host[n]
+    got = {"scores": det.scores[n, :c].cpu().numpy(), "boxes": det.boxes[n, :c].cpu().numpy(),
+           "orientations": None if det.orient is None else det.orient[n, :c].cpu().numpy(),
+           "kept": None if det.kept_index is None else det.kept_index[n, :c].cpu().numpy()}
+    refd = {"scores": ref["scores"].numpy(), "pred_boxes": ref["pred_boxes"].numpy(),
+            "orientations": None if ref.get("orientations") is None else ref["orientations"].numpy(),
+            "kept": None if ref.get("kept") is None else ref["kept"].numpy()}
+    assert_detections_close(got, refd, what=what + " detections")
+
+
 def test_config0_512_pretrain_style_end_to_end_vs_oracle(sd):
     import glass_amd
     from glass_amd.utils.synth import make_image
@@ -32,13 +57,13 @@ def test_config0_512_pretrain_style_end_to_end_vs_oracle(sd):
     m = glass_amd.build_model(cfg)
     m.load_state_dict(sd)
     img = make_image(20, 512, 512).permute(2, 0, 1).float()
-    out = m.inference([{"image": img.cuda()}], do_postprocess=False)[0]
+    res = m.inference([{"image": img.cuda()}], do_postprocess=False)
+    out, det = res[0], res.batch
     ref = O.glass_inference(sd, [img], cfg)[0]
-    assert len(out) == len(ref["scores"]) and len(out) > 0
-    np.testing.assert_allclose(out.scores.cpu().numpy(), ref["scores"].numpy(), atol=1e-3)
-    np.testing.assert_allclose(out.pred_boxes.tensor.cpu().numpy(), ref["pred_boxes"].numpy(), rtol=1e-4, atol=1e-2)
-    p, q = out.pred_text_prob.cpu().numpy(), ref["pred_text_prob"].numpy()
-    assert np.abs(p - q).max() < 5e-3 and (p.argmax(-1) == q.argmax(-1)).mean() > 0.99
+    assert len(out) > 0
+    _compare_proposals(det, 0, ref["proposals"], "configs[0] 512x512")
+    _compare_detections(det, 0, ref, "configs[0] 512x512")
+    assert_text_prob_close(out.pred_text_prob.cpu().numpy(), ref["pred_text_prob"].numpy(), what="configs[0] 512x512 text")
 
 
 def test_config1_backbone_fpn_full_size_vs_oracle(sd):
@@ -98,7 +123,7 @@ def test_config4_textocr_one_image_vs_oracle(sd):
     ref = O.glass_inference(sd2, [img], cfg, injected_boxes=boxes)[0]
     p, q = out.pred_text_prob.cpu().numpy(), ref["pred_text_prob"].numpy()
     assert p.shape == q.shape == (12, 26, 97)
-    assert np.abs(p - q).max() < 5e-3 and (p.argmax(-1) == q.argmax(-1)).mean() > 0.99
+    assert_text_prob_close(p, q, what="configs[4] 1000x1333 one image, 12 RoIs, text")
 
 
 def test_config2_bench_workload_one_image_vs_oracle(sd):
@@ -113,14 +138,16 @@ def test_config2_bench_workload_one_image_vs_oracle(sd):
     img = make_image(0, 1000, 1000).permute(2, 0, 1).float().contiguous()          # bench image 0 (seed 1000 + 0)
     boxes = [make_boxes(0, 32, 1000, 1000)]                                          # bench boxes 0 (seed 2000 + 0)
     ref = O.glass_inference(sd, [img], cfg, injected_boxes=boxes)[0]
-    m.inference([{"image": img.cuda()}], do_postprocess=False, override_boxes=[boxes[0].cuda()])
-    det = m.last_batch
+    res = m.inference([{"image": img.cuda()}], do_postprocess=False, override_boxes=[boxes[0].cuda()])
+    det = res.batch
     p, q = det.text.cpu().numpy(), ref["pred_text_prob"].numpy()
     assert p.shape == q.shape == (32, 26, 97)
-    assert np.abs(p - q).max() < 5e-3 and (p.argmax(-1) == q.argmax(-1)).mean() > 0.99
-    # the box head ran on the real proposals of the image: same proposal set as the oracle's RPN (teacher-free)
-    props = ref["proposals"][0]
-    assert len(props) > 0
+    assert_text_prob_close(p, q, what="configs[2] 1000x1000, 32 RoIs, text")
+    # the RPN and the box head ran teacher-free on the image: same proposals (set, scores), same detections (kept
+    # proposal indices, scores, boxes, orientations) as the oracle
+    assert len(ref["proposals"][0]) > 0
+    _compare_proposals(det, 0, ref["proposals"], "configs[2] 1000x1000")
+    _compare_detections(det.detected, 0, ref, "configs[2] 1000x1000")
 
 
 def test_config4_fp16_conv_mode_tracks_the_fp32_path(sd):
@@ -140,8 +167,8 @@ def test_config4_fp16_conv_mode_tracks_the_fp32_path(sd):
         cfg = _cfg(["MODEL.ORIENTATION_ON", False, "MODEL.CONV_PRECISION", prec])
         m = glass_amd.build_model(cfg)
         m.load_state_dict(sd2)
-        m.inference([{"image": img}], do_postprocess=False, override_boxes=boxes)
-        outs[prec] = (m.last_batch.text.cpu().numpy(), K.last_conv_path())
+        res = m.inference([{"image": img}], do_postprocess=False, override_boxes=boxes)
+        outs[prec] = (res.batch.text.cpu().numpy(), K.last_conv_path())
         assert K.conv_precision() == "fp32"                       # the model restores the global setting
     assert outs["fp16"][1] == "direct_fp16" and outs["fp32"][1] in ("direct", "winograd")
     p, q = outs["fp16"][0], outs["fp32"][0]

@@ -1,0 +1,88 @@
+"""GPU: steps kept in flight by utils.pipeline.run_pipelined give, step for step, what the synchronous API gives -
+per-step state (padded batch, word outputs, conv precision) must not leak between the interleaved steps
+(glass_rcnn.py:100, post_processor_rotated_boxes.py:124)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(opts=()):
+    from glass_amd.config import get_glass_cfg
+    return get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", "cuda:0"] + list(opts))
+
+
+def test_pipelined_steps_with_different_inputs_equal_synchronous_steps():
+    import glass_amd
+    from glass_amd.distributed import pack_words
+    from glass_amd.postprocess import build_post_processor
+    from glass_amd.utils.pipeline import drive, run_pipelined
+    from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
+    cfg = _cfg(["POST_PROCESSING.TEXT_THRESHOLD", 0.0])
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(make_state_dict(1234))
+    post = build_post_processor(cfg)
+    H, W = 160, 224
+    steps = []
+    for s in range(5):                       # five steps, all different (images, boxes, box counts)
+        imgs = [make_image(100 + 2 * s + i, H, W).permute(2, 0, 1).float().contiguous().cuda() for i in range(2)]
+        boxes = [(make_boxes(100 + 2 * s + i, 3 + (s + i) % 3, H, W) * torch.tensor([1, 1, 0.35, 0.5, 1.0])).cuda() for i in range(2)]
+        steps.append((imgs, boxes))
+
+    def make(s):
+        imgs, boxes = steps[s]
+
+        def gen():
+            out = yield from m.inference_g([{"image": im} for im in imgs], override_boxes=boxes)
+            det = out.batch
+            words = yield from post.process_padded_g(det.boxes, det.scores, det.counts_dev, det.text, None, [(H, W)] * 2,
+                                                     {"orientations": det.orient})
+            return pack_words(words.words, 100, 26), det.text.clone()
+        return gen
+
+    sync = [drive(make(s)()) for s in range(5)]
+    for depth in (2, 3):
+        piped = run_pipelined([make(s) for s in range(5)], depth=depth, device=torch.device("cuda:0"))
+        torch.cuda.synchronize()
+        for s in range(5):
+            assert torch.equal(piped[s][0], sync[s][0]), f"depth {depth}: step {s} packed another step's words"
+            assert torch.equal(piped[s][1], sync[s][1]), f"depth {depth}: step {s} text differs"
+    # the steps really are different (the test has teeth)
+    assert not torch.equal(sync[0][0], sync[1][0])
+
+
+def test_conv_precision_does_not_leak_between_in_flight_steps():
+    """an fp16-mode model and an fp32-mode model with steps interleaved: each step's result equals its own
+    synchronous result bit for bit, and the global setting is back to fp32 afterwards."""
+    import glass_amd
+    from glass_amd.ops import native as K
+    from glass_amd.utils.pipeline import drive, run_pipelined
+    from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
+    sd = make_state_dict(1234)
+    models = {}
+    for prec in ("fp32", "fp16"):
+        m = glass_amd.build_model(_cfg(["MODEL.CONV_PRECISION", prec]))
+        m.load_state_dict(sd)
+        models[prec] = m
+    H, W = 128, 160
+    img = make_image(7, H, W).permute(2, 0, 1).float().contiguous().cuda()
+    boxes = [(make_boxes(7, 4, H, W) * torch.tensor([1, 1, 0.35, 0.5, 1.0])).cuda()]
+
+    def make(prec):
+        def gen():
+            out = yield from models[prec].inference_g([{"image": img}], do_postprocess=False, override_boxes=boxes)
+            return out.batch.text.clone()
+        return gen
+
+    ref = {p: drive(make(p)()) for p in ("fp32", "fp16")}
+    assert not torch.equal(ref["fp32"], ref["fp16"])
+    order = ["fp16", "fp32", "fp16", "fp16", "fp32", "fp32", "fp16"]
+    got = run_pipelined([make(p) for p in order], depth=2, device=torch.device("cuda:0"))
+    torch.cuda.synchronize()
+    for p, g in zip(order, got):
+        assert torch.equal(g, ref[p]), f"a {p} step ran (partly) in the other precision"
+    assert K.conv_precision() == "fp32"

@@ -52,20 +52,7 @@ def _nhwc(x):
     return torch.from_numpy(np.ascontiguousarray(x)).permute(0, 2, 3, 1).contiguous().to(_dev())
 
 
-def _assert_same_box_set(got, ref, atol=2e-3, rtol=1e-4):
-    """order-insensitive match (near-tied scores may swap neighbours); angles compared modulo 360."""
-    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    assert got.shape == ref.shape, (got.shape, ref.shape)
-    used = set()
-    for i, r in enumerate(ref):
-        d = np.abs(got - r)
-        d[:, 4] = np.abs((got[:, 4] - r[4] + 180.0) % 360.0 - 180.0)
-        ok = (d <= atol + rtol * np.abs(r)).all(axis=1)
-        cand = [j for j in np.nonzero(ok)[0] if j not in used]
-        assert cand, f"oracle box {i} {r} has no HIP match (closest {got[d.sum(1).argmin()]})"
-        j = min(cand, key=lambda j: abs(j - i))
-        assert abs(j - i) <= 3, f"box {i} matched far away at {j}"
-        used.add(j)
+from parity import assert_same_box_set as _assert_same_box_set  # noqa: E402
 
 
 def _maxdiff(a, b):
@@ -215,16 +202,18 @@ def test_recognizer_branch_matches_oracle_teacher_forced(model, scene, cfg, sd_f
 def test_end_to_end_matches_oracle(model, scene, cfg, sd_full):
     """whole model, both images in one batch: detections (set + values) and character probabilities."""
     from oracle import glass_cpu as O
+    from parity import assert_detections_close, assert_text_prob_close
     ref = O.glass_inference(sd_full, scene["imgs"], cfg)
     out = model.inference([{"image": im} for im in scene["imgs"]], do_postprocess=False)
+    det = out.batch
     for n, (r, o) in enumerate(zip(ref, out)):
-        assert len(o) == len(r["scores"]), f"image {n}: {len(o)} detections vs oracle {len(r['scores'])}"
-        np.testing.assert_allclose(o.scores.cpu().numpy(), r["scores"].numpy(), rtol=0, atol=TOL)
-        np.testing.assert_allclose(o.pred_boxes.tensor.cpu().numpy(), r["pred_boxes"].numpy(), rtol=1e-4, atol=5e-3)
+        got = {"scores": o.scores.cpu().numpy(), "boxes": o.pred_boxes.tensor.cpu().numpy(),
+               "orientations": o.orientations.cpu().numpy(), "kept": det.kept_index[n, :len(o)].cpu().numpy()}
+        refd = {"scores": r["scores"].numpy(), "pred_boxes": r["pred_boxes"].numpy(), "orientations": r["orientations"].numpy(),
+                "kept": r["kept"].numpy()}
+        assert_detections_close(got, refd, what=f"e2e image {n} {IMG_SIZES[n]}")
         if len(o):
-            p, q = o.pred_text_prob.cpu().numpy(), r["pred_text_prob"].numpy()
-            assert (p.argmax(-1) == q.argmax(-1)).mean() > 0.99
-            assert _maxdiff(p, q) < 5e-3
+            assert_text_prob_close(o.pred_text_prob.cpu().numpy(), r["pred_text_prob"].numpy(), what=f"e2e image {n} text")
 
 
 def test_empty_detections_keep_reference_behaviour(model, scene):

@@ -30,7 +30,8 @@ def test_oracle_paste_equals_reference_functions():
     assert int((got.numpy() != out_bool).sum()) == 0
     got8 = O.paste_rotated_masks(masks, boxes, hw, -1)
     assert got8.dtype == torch.uint8
-    assert int(np.abs(got8.numpy().astype(np.int32) - out_u8.astype(np.int32)).max()) <= 1   # fma contraction in sampling
+    # (the golden pastes RoI by RoI, this call pastes the batch: same kernels, same values)
+    assert int(np.abs(got8.numpy().astype(np.int32) - out_u8.astype(np.int32)).max()) == 0
 
 
 def test_deconv_is_a_1x1_conv_plus_pixel_shuffle():
@@ -70,12 +71,17 @@ def test_paste_kernel_matches_reference_golden():
     masks, boxes, hw, out_bool, out_u8 = _golden()
     got = K.paste_rotated_masks(masks.to(_dev()), boxes.to(_dev()), hw, 0.5)
     assert got.dtype == torch.bool
+    # BIT-EXACT: the kernel executes the reference's torch-CPU fp32 operations in their order, fused exactly where torch
+    # fuses (csrc/masks.hip header; the sequence was established by emulation against this golden, which the
+    # reference's own paste_masks_in_image produced): 0 differing pixels, 0 differing bytes
     diff = got.cpu().numpy() != out_bool
-    # the sampled value crosses 0.5 on a contour; fp32 rounding (fma contraction) may flip pixels sitting on it
-    assert diff.sum() <= 6, f"{diff.sum()} pixels differ from the reference paste"
+    print(f"rotated mask paste vs reference golden: {int(diff.sum())} of {diff.size} pixels differ")
+    assert diff.sum() == 0, f"{diff.sum()} pixels differ from the reference paste"
     got8 = K.paste_rotated_masks(masks.to(_dev()), boxes.to(_dev()), hw, -1.0)
     assert got8.dtype == torch.uint8
-    assert int(np.abs(got8.cpu().numpy().astype(np.int32) - out_u8.astype(np.int32)).max()) <= 1
+    d8 = np.abs(got8.cpu().numpy().astype(np.int32) - out_u8.astype(np.int32))
+    print(f"rotated mask paste (uint8 mode) vs reference golden: max |diff| {int(d8.max())}, {int((d8 > 0).sum())} bytes differ")
+    assert int(d8.max()) == 0
 
 
 @pytest.mark.gpu
@@ -90,8 +96,16 @@ def test_paste_kernel_matches_oracle_on_image_sized_canvas():
     ref = O.paste_rotated_masks(masks, boxes, (H, W), 0.5).numpy()
     got = K.paste_rotated_masks(masks.to(_dev()), boxes.to(_dev()), (H, W), 0.5).cpu().numpy()
     assert got.shape == ref.shape
-    on = max(int(ref.sum()), 1)
-    assert (got != ref).sum() <= max(8, on // 2000), f"{(got != ref).sum()} of {on} mask pixels differ"
+    # the only operation the kernel cannot replay bit for bit is torch's SLEEF cos/sin (<= 1 ulp, not always
+    # correctly rounded; the kernel rounds the fp64 value): RoIs whose cos AND sin agree are required to be bit-exact
+    a = torch.deg2rad(boxes[:, 4])
+    cr_c, cr_s = torch.cos(a.double()).float(), torch.sin(a.double()).float()
+    same = ((torch.cos(a) == cr_c) & (torch.sin(a) == cr_s)).numpy()
+    per_roi = (got != ref).reshape(R, -1).sum(1)
+    print(f"paste vs oracle on {H}x{W}: differing pixels per RoI {per_roi.tolist()}, torch cos/sin correctly rounded: {same.tolist()}")
+    assert same.sum() >= R - 2
+    assert int(per_roi[same].sum()) == 0
+    assert int(per_roi[~same].sum()) <= 8 * int((~same).sum())
     assert K.paste_rotated_masks(masks[:0].to(_dev()), boxes[:0].to(_dev()), (H, W)).shape == (0, H, W)
 
 
