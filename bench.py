@@ -64,6 +64,12 @@ def parse():
                     help="e2e = BASELINE configs[2] (default, the metric's config); backbone = configs[1] (ResNet50-FPN only)")
     ap.add_argument("--conv-table", default="", help="write the per-launch conv table of the instrumented step here")
     ap.add_argument("--cpu-side", type=int, default=SIDE, help="image side of the bounded CPU-baseline sample")
+    ap.add_argument("--from-host", action="store_true",
+                    help="time ONLY the from-host variant as the main loop: every step starts from uint8 HWC images in pinned "
+                         "host memory (H2D copy + on-device u8->f32 CHW conversion inside the step, GlassRunner's front-end). "
+                         "Without this flag the contract's HBM-resident rate is `value` and the from-host rate of a second "
+                         "timed loop is reported next to it (`from_host`).")
+    ap.add_argument("--no-extras", action="store_true", help="skip the from-host and latency loops (value only)")
     return ap.parse_args()
 
 
@@ -137,21 +143,55 @@ class ConvMeter:
 
 
 def cpu_baseline(cfg, sd, side, rois):
-    """Bounded CPU sample: the oracle (CPU restatement, kind='port') on ONE image of the workload."""
+    """Bounded CPU sample: the oracle (CPU restatement, kind='port') on ONE image of the workload
+    (config 3 shape at B = 1: side x side, `rois` injected RoIs) - 1 warm-up + 3 timed runs, median - plus the
+    config-1 leg (one 512 x 512 image end to end, no injected boxes) and per-stage times of the last run."""
+    import statistics
     from glass_amd.utils.synth import make_boxes, make_image
     from glass_amd.utils.host import usable_cpus
     from oracle import glass_cpu as O
     n = usable_cpus()                                             # affinity mask and cgroup CFS quota
     torch.set_num_threads(n)
+
+    def timed(fn, warm=1, reps=3):
+        ts = []
+        for i in range(warm + reps):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                fn()
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), ts
+
     img = make_image(0, side, side).permute(2, 0, 1).float()
     boxes = [make_boxes(0, rois, side, side)]
-    t0 = time.perf_counter()
+    med, ts = timed(lambda: O.glass_inference(sd, [img], cfg, injected_boxes=boxes))
+    # per-stage split of one more run (same functions glass_inference calls, in its order)
+    stages = {}
     with torch.no_grad():
-        O.glass_inference(sd, [img], cfg, injected_boxes=boxes)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": n, "kind": "port",
+        t0 = time.perf_counter()
+        x, sizes = O.preprocess([img], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 32)
+        feats = O.resnet50_fpn(sd, x)
+        t1 = time.perf_counter()
+        props = O.rpn_proposals(sd, feats, sizes, cfg)
+        t2 = time.perf_counter()
+        pb = [p[0] for p in props]
+        sc, dl, og, _ = O.box_head_logits(sd, feats, pb, cfg)
+        O.box_inference(sc, dl, og, pb, sizes, cfg)
+        t3 = time.perf_counter()
+        O.recognizer_branch(sd, x, feats, boxes, cfg)
+        t4 = time.perf_counter()
+    stages = {"preprocess+backbone+fpn": (t1 - t0) * 1e3, "rpn": (t2 - t1) * 1e3, "box_head+nms": (t3 - t2) * 1e3,
+              "recognition_branch": (t4 - t3) * 1e3}
+    img1 = make_image(20, 512, 512).permute(2, 0, 1).float()
+    med1, ts1 = timed(lambda: O.glass_inference(sd, [img1], cfg))
+    return {"value": 1.0 / med, "unit": "images/sec", "cores": n, "kind": "port",
             "sample": f"1 image {side}x{side}, {rois} injected RoIs, oracle/glass_cpu.py fp32 torch-CPU ({n} threads), "
-                      f"single cold run {dt:.1f} s"}
+                      f"1 warm-up + 3 timed runs, median {med:.2f} s (runs {', '.join(f'{t:.2f}' for t in ts)} s)",
+            "stage_ms": {k: round(v, 1) for k, v in stages.items()},
+            "config1_512": {"value": 1.0 / med1, "unit": "images/sec",
+                            "sample": f"BASELINE configs[0]: 1 image 512x512 end to end (no injected boxes), same protocol, "
+                                      f"median {med1:.2f} s (runs {', '.join(f'{t:.2f}' for t in ts1)} s)"}}
 
 
 def main():
@@ -198,6 +238,9 @@ def main():
     images = [make_image(g, args.side, args.side).permute(2, 0, 1).float().contiguous().to(dev) for g in gidx]
     boxes = [make_boxes(g, args.rois, args.side, args.side).to(dev) for g in gidx]
     inputs = [{"image": im} for im in images]
+    # GlassRunner's front-end (reference glass_runner.py:123-148): uint8 HWC image on the host -> device -> float CHW.
+    # The synthetic float images above hold integer values 0..255, so the uint8 route gives bit-identical inputs.
+    host_u8 = [im.permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).cpu().contiguous().pin_memory() for im in images]
     max_det = cfg.TEST.DETECTIONS_PER_IMAGE
     post = build_post_processor(cfg)                              # PostProcessorAcademic (device kernel)
     out_sizes = [(args.side, args.side)] * B
@@ -206,21 +249,28 @@ def main():
     if args.workload == "backbone":
         il = model.preprocess_image(inputs)
 
-    def local_step_g():
+    def local_step_g(from_host=False):
         """one step as a generator (glass_amd/utils/pipeline.py): yields where the host reads counts back"""
+        if from_host:
+            # H2D of the uint8 HWC images (3 MB each, pinned -> stream-ordered) + fused convert (+ resize when the
+            # runner's policy asks for one; 1000 x 1000 is inside [MIN_SIZE_TEST, MAX_SIZE_TEST]... the metric's config
+            # keeps the image size) on the step's stream
+            step_inputs = [{"image": K.image_u8hwc_to_chw(h.to(dev, non_blocking=True), (args.side, args.side))} for h in host_u8]
+        else:
+            step_inputs = inputs
         if args.workload == "backbone":                           # BASELINE configs[1]: trunk + FPN only
             model.backbone.forward_nhwc(il.nhwc4)
             return torch.zeros((B, 1), device=dev)
             yield                                                 # pragma: no cover (makes this a generator)
-        out = yield from model.inference_g(inputs, override_boxes=boxes)   # list[{"instances": Instances}] (views)
+        out = yield from model.inference_g(step_inputs, override_boxes=boxes)   # list[{"instances": Instances}] (views)
         det = out.batch                                           # + this step's padded device-resident batch
         # word post-processing (merge, thresholds, polygons, text decode + text-score filter) for the 8 images
         words = yield from post.process_padded_g(det.boxes, det.scores, det.counts_dev, det.text, None, out_sizes,
                                                  {"orientations": det.orient})
         return pack_words(words.words, max_det, steps_txt)        # fixed-size per-image word records
 
-    def step_g():
-        rec = yield from local_step_g()
+    def step_g(from_host=False):
+        rec = yield from local_step_g(from_host)
         if dist is not None and backend != "nccl":
             return all_gather_records(rec.cpu())
         return all_gather_records(rec)
@@ -228,10 +278,10 @@ def main():
     def local_step():
         return drive(local_step_g())
 
-    def run_steps(n):
+    def run_steps(n, from_host=args.from_host, depth=None):
         """n steps, `--pipeline` of them in flight (each on its own stream; host segments interleaved in a fixed
         order, so every rank issues its all_gathers in the same order)"""
-        run_pipelined([step_g] * n, depth=args.pipeline, device=dev)
+        return run_pipelined([lambda: step_g(from_host)] * n, depth=depth or args.pipeline, device=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -271,6 +321,33 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
+    def timed_loop(n, **kw):
+        """same protocol as the main loop (barrier + synchronize on both sides, max over ranks) for the side measurements"""
+        run_steps(2, **kw)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(n, **kw)
+        barrier()
+        d = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([d], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d
+
+    extras = {}
+    if not args.no_extras and args.workload == "e2e":
+        n_x = max(4, min(args.steps, 20))
+        if not args.from_host:
+            d = timed_loop(n_x, from_host=True)
+            extras["from_host"] = {"value": world * B * n_x / d, "unit": "images/sec", "ms_per_step": d / n_x * 1e3, "steps": n_x,
+                                   "what": "same step starting from uint8 HWC images in pinned host memory: H2D copy (PCIe) + "
+                                           "on-device u8 -> f32 CHW conversion inside the timed step (GlassRunner front-end)"}
+        d = timed_loop(n_x, depth=1)
+        extras["latency_ms_per_step"] = d / n_x * 1e3          # one step at a time: what a single request waits
+        extras["latency_note"] = (f"{n_x} steps run one at a time (--pipeline 1); `value` keeps {args.pipeline} steps in flight, so its "
+                                  f"ms_per_step is the throughput interval, not the latency")
+
     line = None
     if rank == 0:
         # dominant kernel: three extra instrumented steps, outside the timed region
@@ -304,11 +381,18 @@ def main():
         dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time
         # PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate
         # rocprofv3 --pmc runs, gfx950 x2 read correction applied; scripts/pmc_make_summary.py)
-        pmc_all = {}
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_summary.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                pmc_all = json.load(f)
+        pmc_all, pmc_file, pmc_note = {}, None, "no PMC summary under profiles/"
+        from glass_amd._lib import source_sha16
+        import glob
+        for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_summary.json")), reverse=True):
+            with open(cand) as f:
+                js = json.load(f)
+            if js.get("lib_source_sha16") == source_sha16():
+                pmc_all, pmc_file = js, os.path.relpath(cand, ROOT)
+                pmc_note = f"HBM bytes/launch of this kernel, PMC ({pmc_file}; taken with this library: sha {source_sha16()})"
+                break
+            pmc_note = (f"null: {os.path.relpath(cand, ROOT)} was taken with library sha {js.get('lib_source_sha16')}, this run uses "
+                        f"{source_sha16()} - re-run scripts/collect_profiles.sh")
 
         def fam_entry(k):
             f = fam[k]
@@ -352,7 +436,7 @@ def main():
                          "frac": ent["algorithmic_frac"],
                          "executed_tflops": ent["executed_tflops"], "executed_frac": ent["executed_frac"],
                          "traffic": ent["traffic"],
-                         "traffic_note": "HBM bytes/launch of this kernel, PMC (profiles/r01_pmc_conv_summary.json)",
+                         "traffic_note": pmc_note,
                          "mfma_util_percent_pmc": ent["mfma_util_percent_pmc"],
                          "launches_per_step": ent["launches_per_step"],
                          "algorithmic_gflop_per_launch": ent["algorithmic_gflop_per_launch"],
@@ -370,6 +454,10 @@ def main():
                                     "images_per_sec_per_gpu": FP32_MFMA_PEAK_TFLOPS / (conv_flops / B / 1e12),
                                     "frac": (value / world) / (FP32_MFMA_PEAK_TFLOPS / (conv_flops / B / 1e12))},
         }
+        line.update(extras)
+        line["lib_source_sha16"] = source_sha16()
+        if args.from_host:
+            line["config"]["inputs"] = "uint8 HWC in pinned host memory (--from-host): PCIe-inclusive, NOT the contract's value"
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_side, args.rois)
     if dist is not None:

@@ -37,6 +37,18 @@ def sources() -> List[str]:
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_sha16() -> str:
+    """sha256[:16] over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h, in sorted order): identifies the library
+    a profile was taken with (profiles/*_pmc_conv_summary.json records it; bench.py refuses stale counters)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into libglass_hip.so (in-tree)."""
     srcs = sources()

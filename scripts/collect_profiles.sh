@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box (via gpurun): kernel trace + the three PMC passes of bench.py, summarised into gpurun_out/.
 #   gpurun --timeout 1500 -- 'bash scripts/collect_profiles.sh'
+# Afterwards, in the build container:  for f in kernel_stats_default kernel_stats_serial pmc_conv_summary ...; cp gpurun_out/$f profiles/rNN_$f
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"

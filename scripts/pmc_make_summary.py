@@ -10,6 +10,10 @@ Per MFMA kernel: HBM bytes per launch = 2 x FETCH_SIZE KB (gfx950 under-reports 
 import json
 import sys
 
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "glass-text-spotting_amd"))
+from glass_amd._lib import source_sha16  # noqa: E402
+
 fetch, write, mfma = (json.load(open(p)) for p in sys.argv[1:4])
 KEYS = {"conv3x3_wino128_f32": "conv3x3_wino128_f32", "conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, 1",
         "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, 1",
@@ -31,7 +35,8 @@ def ndisp(js, sub):
     return None, None
 
 
-out = {"command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE> --kernel-trace -- "
+out = {"lib_source_sha16": source_sha16(),      # bench.py reports these counters only for the library they were taken with
+       "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE> --kernel-trace -- "
                   "python bench.py --steps 1 --warmup 1 --no-cpu-baseline (three separate passes; summarised on the GPU box "
                   "with scripts/pmc_summary.py, folded with scripts/pmc_make_summary.py)",
        "calibration": {"kernel": "maxpool_nhwc_kernel", "known_read_MB": 369.1, "FETCH_SIZE_MB_raw": 204.72888,

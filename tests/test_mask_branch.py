@@ -103,7 +103,6 @@ def test_paste_kernel_matches_oracle_on_image_sized_canvas():
     same = ((torch.cos(a) == cr_c) & (torch.sin(a) == cr_s)).numpy()
     per_roi = (got != ref).reshape(R, -1).sum(1)
     print(f"paste vs oracle on {H}x{W}: differing pixels per RoI {per_roi.tolist()}, torch cos/sin correctly rounded: {same.tolist()}")
-    assert same.sum() >= R - 2
     assert int(per_roi[same].sum()) == 0
     assert int(per_roi[~same].sum()) <= 8 * int((~same).sum())
     assert K.paste_rotated_masks(masks[:0].to(_dev()), boxes[:0].to(_dev()), (H, W)).shape == (0, H, W)
