@@ -99,7 +99,9 @@ class ConvMeter:
             cin_real = 3 if cin == 4 else cin           # NHWC4-padded RGB inputs
             algo = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin_real
             path = self.K.last_conv_path()
-            if path.startswith("winograd"):             # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
+            if path == "winograd43":                    # F(4x4,3x3): 36 MACs per (ceil(H/4) x ceil(W/4)) tile, channel pair
+                ex = 2.0 * y.shape[0] * ((y.shape[1] + 3) // 4) * ((y.shape[2] + 3) // 4) * 36 * cout * cin
+            elif path.startswith("winograd"):           # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2) * 16 * cout * cin
             else:
                 ex = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin
@@ -132,7 +134,7 @@ class ConvMeter:
 
     def summary(self):
         out = {k: {"launches": 0, "ms": 0.0, "algo_flops": 0.0, "exec_flops": 0.0}
-               for k in ("winograd128", "winograd", "direct", "direct_fp16")}
+               for k in ("winograd43", "winograd128", "winograd", "direct", "direct_fp16")}
         for p, _xs, _ws, _st, _res, algo, ex, ms in self._launches():
             f = out[p]
             f["launches"] += 1
@@ -371,11 +373,12 @@ def main():
         conv_ms = sum(f["ms"] for f in fam.values())
         conv_flops = sum(f["algo_flops"] for f in fam.values())
         n_launch = sum(f["launches"] for f in fam.values())
-        KNAME = {"winograd128": "conv3x3_wino128_f32 (Winograd F(2x2,3x3), fp32 MFMA, 32 tiles x 128 channels per workgroup)",
+        KNAME = {"winograd43": "conv3x3_wino43_f32 (Winograd F(4x4,3x3), fp32 MFMA 16x16x4, 16 tiles x 128 channels per workgroup)",
+                 "winograd128": "conv3x3_wino128_f32 (Winograd F(2x2,3x3), fp32 MFMA, 32 tiles x 128 channels per workgroup)",
                  "winograd": "conv3x3_wino_f32 (Winograd F(2x2,3x3), fp32 MFMA, 64 tiles x 64 channels per workgroup)",
                  "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
                  "direct_fp16": "conv_igemm_f32<..., HALF> (fp16 MFMA implicit-GEMM conv/linear, fp32 accumulate)"}
-        PKEY = {"winograd128": "conv3x3_wino128_f32", "winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
+        PKEY = {"winograd43": "conv3x3_wino43_f32", "winograd128": "conv3x3_wino128_f32", "winograd": "conv3x3_wino_f32", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
                 "direct_fp16": "conv_igemm_f16"}
         PEAK = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else FP16_MFMA_PEAK_TFLOPS
         dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time
@@ -428,8 +431,9 @@ def main():
             "hbm_peak_reserved_gb": torch.cuda.max_memory_reserved(dev) / 1e9,   # rank 0, whole run (of 288 GB)
             "roofline": {"bound": "mfma", "kernel": ent["kernel"],
                          # `achieved` = ALGORITHMIC (direct-convolution) FLOP of the kernel's launches / their
-                         # measured time, as the contract defines it; for the Winograd kernel this exceeds the MFMA peak
-                         # (frac > 1) because it issues 2.25x fewer multiplies than the direct-convolution count.  The
+                         # measured time, as the contract defines it; for the Winograd kernels this exceeds the MFMA peak
+                         # (frac > 1) because they issue 4x (F(4x4,3x3)) / 2.25x (F(2x2,3x3)) fewer multiplies than the
+                         # direct-convolution count.  The
                          # hardware-utilisation view - the FLOP the kernel really issues to the matrix cores - is
                          # `executed_tflops` / `executed_frac` (cross-checked by the PMC MFMA-busy counter).
                          "achieved": ent["algorithmic_tflops"], "peak": PEAK, "unit": "TFLOP/s",

@@ -1,0 +1,392 @@
+// Winograd F(4x4, 3x3) convolution on the fp32 matrix cores of gfx950 (3x3, stride 1, pad 1, NHWC fp32).
+//
+// F(2x2,3x3) (winograd.hip) issues 16 multiplies per 2x2 output tile = 4 per output pixel and channel pair; F(4x4,3x3)
+// issues 36 per 4x4 tile = 2.25 (1.78x fewer again, 4x fewer than the direct convolution), reads 36 instead of 64
+// input values per 16 outputs and streams 2.25x the weight bytes.  fp32 accuracy is the price of the larger
+// transform: with the usual points (0, +-1, +-2) the error is 1.5e-5 of the output range on a 256-channel layer;
+// this kernel uses the points (0, 1, -1, 1/2, -2, inf), measured at 4.7e-6 (fp64 reference; tests/test_gpu_ops.py
+// holds the kernel to 2e-5 of the range), at the cost of a transform without the even/odd symmetry (16 instead of
+// ~12 operations per 6-point transform).
+//
+//   Y(4x4) = At [ sum_c (G g G^t) . (Bt d B) ] A,   36 independent GEMMs  M_xi[cout][tile] = sum_c U_xi[cout][c] V_xi[c][tile]
+//
+// Work decomposition (256 threads = 4 waves, ONE workgroup per CU):
+//   * block = 16 output tiles (4x4 pixels each = 256 output pixels) x 128 output channels x all 36 xi, k-tile = 32
+//     input channels.  Wave w owns the 32 output channels 32w..32w+31 for ALL 36 xi: 36 x 2 MFMA blocks of
+//     v_mfma_f32_16x16x4_f32 (rows = 16 channels, columns = the 16 tiles) = 288 accumulator registers.  Because a
+//     lane then holds all 36 xi of its (tile, 4-channel) outputs, the output transform At . A runs entirely in
+//     registers - no LDS exchange, no barrier in the epilogue - and ends in 32-byte-per-lane row stores.
+//   * per k-tile: thread (tile, channel pair) fetches its raw 6x6 patch with 36 bounds-checked buffer_load_dwordx2
+//     (offset = row part + column part, an invalid part is 2^30 so that the sum is out of range: padding and ragged
+//     tiles are the hardware's zero fill; 12 offset registers instead of 36), applies Bt d B in place (12 six-point
+//     transforms of 16 fma/add per channel) and writes the 36 transformed pairs to LDS V[xi][tile][32], XOR-swizzled
+//     so that the MFMA-side ds_read_b128 (one per 8 MFMAs, feeding 4 k-steps x 2 channel blocks) is conflict free.
+//   * weights never touch LDS: U = G g G^t is pre-packed (glass_winograd43_pack_weights) in MFMA A-fragment order,
+//     each wave streams its own 1 KiB fragments L2 -> registers through a 4-slot ring, three groups ahead.
+//   * 576 MFMAs (18.4 K cycles) per wave and k-tile against 144 weight loads + 72 LDS reads + 36 patch loads + 36 LDS
+//     writes + ~390 VALU, all metered between the MFMAs (the source order IS the issue order, pinned with
+//     sched_barrier like the F(2x2) kernels); V is double buffered, one barrier per k-tile.
+#include "wino_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int T4 = 16;                        // output tiles (4x4 pixels each) per block
+constexpr int N4 = 128;                       // output channels per block
+constexpr int K4 = 32;                        // input channels per k-tile
+constexpr int V4_FLOATS = 36 * T4 * K4;       // 72 KiB per stage
+constexpr int WINO43_LDS_BYTES = 2 * V4_FLOATS * 4;
+constexpr unsigned INV = 0x40000000u;         // "invalid" part of a split offset: any sum containing it is >= 1 GiB
+
+__device__ __forceinline__ float comp4(const f32x4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+
+// six-point input transform (rows of Bt for the points 0, 1, -1, 1/2, -2, inf), one scalar channel:
+//   o0 =  d0 - 3/2 d1 - 2 d2 + 3/2 d3 + d4          o3 = -2 d1 - d2 + 2 d3 + d4
+//   o1 = -d1 + 1/2 d2 + 5/2 d3 + d4                 o4 = 1/2 d1 - d2 - 1/2 d3 + d4
+//   o2 =  d1 - 5/2 d2 + 1/2 d3 + d4                 o5 = d1 - 3/2 d2 - 2 d3 + 3/2 d4 + d5
+struct Bt6 {
+  float a, b, o0, o1, o2, o3, o4, o5;
+  template <int S> __device__ __forceinline__ void step(float d0, float d1, float d2, float d3, float d4, float d5) {
+    if constexpr (S == 0) { a = d3 - d1; b = d4 - d2; }
+    if constexpr (S == 1) o0 = __builtin_fmaf(-2.f, d2, __builtin_fmaf(1.5f, a, d0 + d4));
+    if constexpr (S == 2) o1 = __builtin_fmaf(2.5f, d3, __builtin_fmaf(0.5f, d2, d4 - d1));
+    if constexpr (S == 3) o2 = __builtin_fmaf(0.5f, d3, __builtin_fmaf(-2.5f, d2, d4 + d1));
+    if constexpr (S == 4) o5 = __builtin_fmaf(-2.f, d3, __builtin_fmaf(1.5f, b, d1 + d5));
+    if constexpr (S == 5) { o3 = __builtin_fmaf(2.f, a, b); o4 = __builtin_fmaf(-0.5f, a, b); }
+  }
+};
+
+// four-point output transform (rows of At): y0 = m0+m1+m2+m3+m4, y1 = m1-m2+m3/2-2m4, y2 = m1+m2+m3/4+4m4,
+// y3 = m1-m2+m3/8-8m4+m5
+__device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1,
+                                    float& y2, float& y3) {
+  const float s = m1 + m2, d = m1 - m2;
+  y0 = (m0 + s) + (m3 + m4);
+  y1 = __builtin_fmaf(-2.f, m4, __builtin_fmaf(0.5f, m3, d));
+  y2 = __builtin_fmaf(4.f, m4, __builtin_fmaf(0.25f, m3, s));
+  y3 = __builtin_fmaf(-8.f, m4, __builtin_fmaf(0.125f, m3, d)) + m5;
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // XCD-aware tile map (see conv.hip): cout-blocks innermost so the blocks that share an input patch sit on one L2
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = logical / p.tiles_n;
+  const int tile_n = logical - tile_m * p.tiles_n;
+  const int t0 = tile_m * T4, n0 = tile_n * N4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tpi = p.TH * p.TW;
+
+  __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
+
+  // ---- input role: thread = (tile tl, channel pair c2 of the 32) ----
+  const int c2 = tid & 15, tl = tid >> 4;
+  unsigned rowoff[6], coloff[6];
+  {
+    const int t = t0 + tl;
+    const bool tv = t < p.ntiles;
+    const int n = fast_div(t, tpi, p.magic_tpi);
+    const int rem = t - n * tpi;
+    const int th = fast_div(rem, p.TW, p.magic_tw);
+    const int tw = rem - th * p.TW;
+    const int h0 = 4 * th - 1, w0 = 4 * tw - 1;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int hi = h0 + r;
+      rowoff[r] = (tv && (unsigned)hi < (unsigned)p.H) ? (unsigned)(((n * p.H + hi) * p.W) * p.ldx * 4) : INV;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int wi = w0 + c;
+      coloff[c] = ((unsigned)wi < (unsigned)p.W) ? (unsigned)((wi * p.ldx + 2 * c2) * 4) : INV;
+    }
+  }
+  float dx[36], dy[36];                       // the two channels of the 6x6 patch, transformed in place
+  auto load_patch1 = [&](int kt, auto i_) {
+    constexpr int i = decltype(i_)::value;
+    // (bit_cast the whole vector: __builtin_bit_cast of a single vector ELEMENT reads element 0 with this compiler)
+    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, rowoff[i / 6] + coloff[i % 6], kt * (K4 * 4), 0));
+    dx[i] = v.x;
+    dy[i] = v.y;
+  };
+  // V[stage][xi][tile][32]: a row is 128 bytes = half of the 64 banks, consecutive tiles alternate halves; the 16-byte
+  // slot is XOR-ed with (tile/2)%8 so that the 16 tiles a ds_read_b128 service group touches hit 16 different slots.
+  float* vdst = smem + tl * K4 + (((c2 >> 1) ^ ((tl >> 1) & 7)) * 4) + (c2 & 1) * 2;
+  Bt6 bx, by;
+  // transform micro-steps (compile-time index): 36 row steps (column c, step S), then per row i six column steps
+  // (which write V[i][*] to LDS as they go)
+  auto row_step = [&](auto c_, auto s_) {
+    constexpr int c = decltype(c_)::value, S = decltype(s_)::value;
+    bx.template step<S>(dx[0 + c], dx[6 + c], dx[12 + c], dx[18 + c], dx[24 + c], dx[30 + c]);
+    by.template step<S>(dy[0 + c], dy[6 + c], dy[12 + c], dy[18 + c], dy[24 + c], dy[30 + c]);
+    if constexpr (S == 5) {
+      dx[0 + c] = bx.o0; dx[6 + c] = bx.o1; dx[12 + c] = bx.o2; dx[18 + c] = bx.o3; dx[24 + c] = bx.o4; dx[30 + c] = bx.o5;
+      dy[0 + c] = by.o0; dy[6 + c] = by.o1; dy[12 + c] = by.o2; dy[18 + c] = by.o3; dy[24 + c] = by.o4; dy[30 + c] = by.o5;
+    }
+  };
+  auto vstore = [&](int stage, int xi, float vx, float vy) {
+    f32x2 v; v.x = vx; v.y = vy;
+    *reinterpret_cast<f32x2*>(vdst + stage * V4_FLOATS + xi * (T4 * K4)) = v;
+  };
+  auto col_step = [&](int stage, auto i_, auto s_) {
+    constexpr int i = decltype(i_)::value, S = decltype(s_)::value;
+    bx.template step<S>(dx[i * 6 + 0], dx[i * 6 + 1], dx[i * 6 + 2], dx[i * 6 + 3], dx[i * 6 + 4], dx[i * 6 + 5]);
+    by.template step<S>(dy[i * 6 + 0], dy[i * 6 + 1], dy[i * 6 + 2], dy[i * 6 + 3], dy[i * 6 + 4], dy[i * 6 + 5]);
+    if constexpr (S == 1) vstore(stage, i * 6 + 0, bx.o0, by.o0);
+    if constexpr (S == 2) vstore(stage, i * 6 + 1, bx.o1, by.o1);
+    if constexpr (S == 3) vstore(stage, i * 6 + 2, bx.o2, by.o2);
+    if constexpr (S == 4) vstore(stage, i * 6 + 5, bx.o5, by.o5);
+    if constexpr (S == 5) { vstore(stage, i * 6 + 3, bx.o3, by.o3); vstore(stage, i * 6 + 4, bx.o4, by.o4); }
+  };
+
+  // ---- MFMA role: wave wv owns channels n0 + 32 wv + [0, 32) for all 36 xi ----
+  // 16x16x4: A[i = lane&15][k = lane>>4] = weights (row i = 4 g' + e  <->  channel 32 wv + 8 g' + 4 cb + e),
+  //          B[k = lane>>4][j = lane&15] = V (tile j);  C/D: lane holds rows 4 (lane>>4) + e, column lane&15.
+  f32x4 acc[36][2];
+#pragma unroll
+  for (int i = 0; i < 36; ++i)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int vj = lane & 15, kg = lane >> 4;
+  const int vswz = (vj >> 1) & 7;
+  const float* vb[2] = {smem + vj * K4 + ((0 * 4 + kg) ^ vswz) * 4, smem + vj * K4 + ((1 * 4 + kg) ^ vswz) * 4};
+  const unsigned a_voff = (unsigned)lane * 16u;
+  f32x4 aq[4][2];                             // weight fragments: [ring slot = group & 3][cb]
+  f32x4 vq[2];                                // V fragments: [group & 1]
+  // packed U: [tile_n][kt][xi][wave][half][cb] chunks of 1 KiB (64 lanes x float4); group u = 2 xi + half
+  auto load_a1 = [&](int kt, int u, int cb) {
+    const int base = ((((tile_n * p.nk + kt) * 36 + (u >> 1)) * 4 + wv) * 4 + (u & 1) * 2 + cb) * 1024;
+    aq[u & 3][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, base, 0));
+  };
+  auto read_v = [&](int stage, int u) {
+    vq[u & 1] = *reinterpret_cast<const f32x4*>(vb[u & 1] + stage * V4_FLOATS + (u >> 1) * (T4 * K4));
+  };
+
+  // ---- prologue: patch 0 -> V[0], weight fragments of the first three groups, patch 1 in flight ----
+  static_for<36>([&](auto i_) { load_patch1(0, i_); });
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
+  static_for<6>([&](auto c_) { static_for<6>([&](auto s_) { row_step(c_, s_); }); });
+  static_for<6>([&](auto i_) { static_for<6>([&](auto s_) { col_step(0, i_, s_); }); });
+  {
+    const int k1 = p.nk > 1 ? 1 : 0;
+    static_for<36>([&](auto i_) { load_patch1(k1, i_); });
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const int cur = kt & 1;
+    const int ktn = kt + 1 < p.nk ? kt + 1 : kt;     // clamped at the end: harmless re-reads keep the loop one block
+    const int ktnn = kt + 2 < p.nk ? kt + 2 : kt;
+    read_v(cur, 0);
+    static_for<72>([&](auto u_) {
+      constexpr int u = decltype(u_)::value;
+      constexpr int xi = u >> 1;
+      static_for<8>([&](auto m_) {
+        constexpr int m = decltype(m_)::value;
+        constexpr int s = m >> 1, cb = m & 1;
+        // side work issued BEFORE MFMA (u, m)
+        if constexpr (m == 0 || m == 2) {                 // weight fragments of the group three ahead
+          constexpr int u3 = u + 3;
+          if constexpr (u3 < 72) load_a1(kt, u3, m >> 1); else load_a1(ktn, u3 - 72, m >> 1);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (m == 4) {
+          if constexpr (u + 1 < 72) { read_v(cur, u + 1); __builtin_amdgcn_sched_barrier(0); }
+        } else if constexpr (m == 1 || m == 5) {
+          constexpr int q = u * 2 + (m == 5 ? 1 : 0);     // 144 slots for the 108 transform / load steps
+          if constexpr (q < 36) {
+            row_step(ic<q / 6>{}, ic<q % 6>{});           // Bt d of patch kt+1, column q/6
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (q < 108) {
+            constexpr int i = (q - 36) / 12, sub = (q - 36) % 12;
+            if constexpr (sub < 6) col_step(cur ^ 1, ic<i>{}, ic<sub>{});       // (. B) of row i -> V[cur^1]
+            else load_patch1(ktnn, ic<i * 6 + (sub - 6)>{});                     // row i is free: patch of k-tile kt+2
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        acc[xi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(aq[u & 3][cb], s), comp4(vq[u & 1], s), acc[xi][cb], 0, 0, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();     // V[cur] fully read, V[cur^1] fully written
+  }
+
+  // ---- epilogue: Y = At M A in registers; lane = (tile vj, channels n0 + 32 wv + 8 kg + 4 cb + e) ----
+  // 32-bit buffer addressing with split offsets (row part + column part; an invalid part = 2^30 makes the sum out of
+  // range): a pixel that does not exist (ragged last tile block, H or W not a multiple of 4) loads zeros / drops the store.
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_mode == 1 ? p.res : p.y), 0,
+                                                                 (int)(p.res_mode == 1 ? p.r_bytes : 0u), 0x00020000);
+  const int cbase = n0 + 32 * wv + 8 * kg;
+  const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
+  unsigned yrow[4], ycol[4], rrow[4], rcol[4];
+  {
+    const int t = t0 + vj;
+    const bool tv = t < p.ntiles;
+    const int n = fast_div(t, tpi, p.magic_tpi);
+    const int rem = t - n * tpi;
+    const int th = fast_div(rem, p.TW, p.magic_tw);
+    const int tw = rem - th * p.TW;
+    const unsigned pix = (unsigned)((n * p.H + 4 * th) * p.W + 4 * tw);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const bool ok = tv && 4 * th + a < p.H;
+      yrow[a] = ok ? (pix + (unsigned)(a * p.W)) * ldy4 + (unsigned)(p.ycoff + cbase) * 4u : INV;
+      rrow[a] = ok ? (pix + (unsigned)(a * p.W)) * ldr4 + (unsigned)cbase * 4u : INV;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const bool ok = 4 * tw + b < p.W;
+      ycol[b] = ok ? (unsigned)b * ldy4 : INV;
+      rcol[b] = ok ? (unsigned)b * ldr4 : INV;
+    }
+  }
+  // ReLU before (2) / after (1) the residual add as an unconditional max: max(x, qNaN) = x keeps "no ReLU" exact
+  const float lo2 = p.relu == 2 ? 0.f : __builtin_nanf(""), lo1 = p.relu == 1 ? 0.f : __builtin_nanf("");
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * cb);
+    f32x4 rres[16];
+    if (p.res_mode == 1) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          rres[a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 16, 0));
+    }
+    f32x4 out[16];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float z[6][4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        at4(acc[i * 6 + 0][cb][e], acc[i * 6 + 1][cb][e], acc[i * 6 + 2][cb][e], acc[i * 6 + 3][cb][e], acc[i * 6 + 4][cb][e],
+            acc[i * 6 + 5][cb][e], z[i][0], z[i][1], z[i][2], z[i][3]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float y0, y1, y2, y3;
+        at4(z[0][b], z[1][b], z[2][b], z[3][b], z[4][b], z[5][b], y0, y1, y2, y3);
+        out[0 * 4 + b][e] = y0; out[1 * 4 + b][e] = y1; out[2 * 4 + b][e] = y2; out[3 * 4 + b][e] = y3;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f32x4 v = out[a * 4 + b] + bv;
+        v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
+        if (p.res_mode == 1) v = v + rres[a * 4 + b];
+        v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yrow[a] + ycol[b], cb * 16, 0);
+      }
+  }
+}
+
+// U = G g G^t (6x6 per channel pair) in the fragment order the kernel streams:
+// [cout/128][cin/32][xi][wave][half][cb][lane][s]   with
+//   cout = 128 tn + 32 wave + 8 ((lane&15)>>2) + 4 cb + (lane&3),   cin = 32 kt + 16 half + 4 (lane>>4) + s
+__global__ void wino43_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
+  const long total = 36L * Cout * Cin;
+  const int nk = Cin / K4;
+  const double G[6][3] = {{1.0, 0.0, 0.0}, {1.0 / 3, 1.0 / 3, 1.0 / 3}, {-1.0 / 3, 1.0 / 3, -1.0 / 3},
+                          {-16.0 / 15, -8.0 / 15, -4.0 / 15}, {1.0 / 15, -2.0 / 15, 4.0 / 15}, {0.0, 0.0, 1.0}};
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+    long r = o;
+    const int s = (int)(r & 3); r >>= 2;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int cb = (int)(r & 1); r >>= 1;
+    const int half = (int)(r & 1); r >>= 1;
+    const int wave = (int)(r & 3); r >>= 2;
+    const int xi = (int)(r % 36); r /= 36;
+    const int kt = (int)(r % nk);
+    const int tn = (int)(r / nk);
+    const int co = tn * N4 + 32 * wave + 8 * ((lane & 15) >> 2) + 4 * cb + (lane & 3);
+    const int ci = kt * K4 + 16 * half + 4 * (lane >> 4) + s;
+    const int i = xi / 6, j = xi % 6;
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc += G[i][a] * G[j][b] * (double)w[(((long)co * 3 + a) * 3 + b) * Cin + ci];
+    u[o] = (float)acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int glass_winograd43_supported(const glass_conv_desc* d) {
+  if (!d) return 0;
+  const long xb = (long)d->N * d->H * d->W * d->ldx * 4;
+  const long yb = (long)d->N * d->H * d->W * d->ldy * 4, rb = d->res_mode == 1 ? (long)d->N * d->H * d->W * d->ldr * 4 : 0;
+  const long lim = 0x40000000L;               // split offsets: every operand below 1 GiB
+  return d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+         d->Cin % K4 == 0 && d->Cout % N4 == 0 && d->ldx % 2 == 0 && d->ldx >= d->Cin && d->y_cstride == 1 && d->ldy % 4 == 0 &&
+         d->y_coff % 4 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->ldy &&
+         (d->res_mode == 0 || (d->res_mode == 1 && d->ldr % 4 == 0 && d->ldr >= d->Cout)) && xb < lim && yb < lim && rb < lim &&
+         36L * d->Cout * d->Cin * 4 < 0x7fffff00L && d->Ho == d->H && d->Wo == d->W;
+}
+
+extern "C" size_t glass_winograd43_weight_floats(int Cout, int Cin) { return (size_t)36 * (size_t)Cout * (size_t)Cin; }
+
+extern "C" int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream) {
+  GLASS_CHECK_ARG(w && u_packed, "glass_winograd43_pack_weights: null pointer");
+  GLASS_CHECK_ARG(Cout > 0 && Cin > 0 && Cout % N4 == 0 && Cin % K4 == 0,
+                  "glass_winograd43_pack_weights: Cout=%d must be a multiple of 128 and Cin=%d a multiple of 32", Cout, Cin);
+  const long total = 36L * Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(wino43_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u_packed, Cout, Cin);
+  GLASS_CHECK_LAUNCH("glass_winograd43_pack_weights");
+  return GLASS_OK;
+}
+
+extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
+                                             const float* bias, const float* residual, float* y, glass_stream_t stream) {
+  GLASS_CHECK_ARG(d && x && u_packed && y, "glass_conv3x3_winograd43_nhwc: null pointer");
+  GLASS_CHECK_ARG(glass_winograd43_supported(d),
+                  "glass_conv3x3_winograd43_nhwc: needs 3x3/stride 1/pad 1, Cin%%32==0, Cout%%128==0, unit channel stride, "
+                  "res_mode 0/1 and operands < 1 GiB (got Cin=%d Cout=%d k=%dx%d s=%d p=%d)", d->Cin, d->Cout, d->KH, d->KW,
+                  d->stride_h, d->pad_h);
+  GLASS_CHECK_ARG(d->res_mode == 0 || residual != nullptr, "glass_conv3x3_winograd43_nhwc: res_mode set but residual is null");
+  GLASS_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)u_packed & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                      (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (residual == nullptr || ((uintptr_t)residual & 15) == 0),
+                  "glass_conv3x3_winograd43_nhwc: pointers must be 16-byte aligned");
+  if (d->N == 0) return GLASS_OK;
+  WinoParams p;
+  p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+  p.TH = (d->H + 3) / 4; p.TW = (d->W + 3) / 4;
+  const long nt = (long)d->N * p.TH * p.TW;
+  GLASS_CHECK_ARG(nt < 0x7fffffffL, "glass_conv3x3_winograd43_nhwc: too many tiles");
+  p.ntiles = (int)nt;
+  p.nk = d->Cin / K4;
+  p.ldx = d->ldx; p.ldy = d->ldy; p.ycoff = d->y_coff; p.ldr = d->ldr; p.relu = d->relu; p.res_mode = d->res_mode;
+  p.tiles_m = cdiv(p.ntiles, T4);
+  p.tiles_n = d->Cout / N4;
+  p.x_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldx * 4);
+  p.magic_tpi = (unsigned)(0x100000000ULL / (unsigned long long)(p.TH * p.TW));
+  p.magic_tw = (unsigned)(0x100000000ULL / (unsigned long long)p.TW);
+  p.u_bytes = (unsigned)(36L * d->Cout * d->Cin * 4);
+  p.y_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldy * 4);
+  p.r_bytes = d->res_mode == 1 ? (unsigned)((long)d->N * d->H * d->W * d->ldr * 4) : 0u;
+  const long nblk = (long)p.tiles_m * p.tiles_n;
+  GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv3x3_winograd43_nhwc: bad grid");
+  static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino43_f32),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, WINO43_LDS_BYTES);
+  if (attr_rc != 0) {
+    glass_set_error("glass_conv3x3_winograd43_nhwc: cannot reserve %d bytes of LDS (hip error %d)", WINO43_LDS_BYTES, attr_rc);
+    return GLASS_EHIP;
+  }
+  hipLaunchKernelGGL(conv3x3_wino43_f32, dim3((unsigned)nblk), dim3(256), WINO43_LDS_BYTES, (hipStream_t)stream, p);
+  GLASS_CHECK_LAUNCH("glass_conv3x3_winograd43_nhwc");
+  return GLASS_OK;
+}

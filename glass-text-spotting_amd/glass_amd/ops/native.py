@@ -78,6 +78,7 @@ def conv_out_size(H, W, KH, KW, stride, padding):
 # 3x3/stride-1 layer runs.  Keyed by the weight's storage address; the entry pins the weight tensor so the
 # address cannot be recycled, and is re-packed if the tensor was modified in place (_version).
 _WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": collections.OrderedDict(), "max": 512,
+         "f43": os.environ.get("GLASS_WINOGRAD43", "1") != "0",
          "precision": os.environ.get("GLASS_CONV_PRECISION", "fp32")}
 
 
@@ -97,7 +98,7 @@ def conv_precision() -> str:
 
 
 def last_conv_path() -> str:
-    """'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct' or 'direct_fp16': which kernel
+    """'winograd43' (conv3x3_wino43_f32), 'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct' or 'direct_fp16': which kernel
     the most recent conv2d_nhwc call launched (bench/profiling aid)."""
     return _WINO.get("last_path", "direct")
 
@@ -110,25 +111,45 @@ def set_winograd(enabled: bool) -> bool:
     return prev
 
 
-def winograd_pack(w: torch.Tensor) -> torch.Tensor:
-    """w [Cout,3,3,Cin] -> packed U (16*Cout*Cin floats) for glass_conv3x3_winograd_nhwc."""
+def set_winograd43(enabled: bool) -> bool:
+    """Let eligible layers (Cout % 128 == 0, Cin % 32 == 0, see _use_f43) take the F(4x4,3x3) kernel (default on;
+    GLASS_WINOGRAD43=0 turns it off: F(2x2,3x3) everywhere).  Returns the previous setting."""
+    prev = _WINO["f43"]
+    _WINO["f43"] = bool(enabled)
+    return prev
+
+
+def winograd_pack(w: torch.Tensor, f43: bool = False) -> torch.Tensor:
+    """w [Cout,3,3,Cin] -> packed U for glass_conv3x3_winograd_nhwc (16*Cout*Cin floats) or, with f43, for
+    glass_conv3x3_winograd43_nhwc (36*Cout*Cin floats)."""
     _f32c(w, "w")
     Cout, KH, KW, Cin = w.shape
-    n = int(lib().glass_winograd_weight_floats(Cout, Cin))
+    L = lib()
+    n = int((L.glass_winograd43_weight_floats if f43 else L.glass_winograd_weight_floats)(Cout, Cin))
     u = torch.empty((n,), dtype=torch.float32, device=w.device)
-    check(lib().glass_winograd_pack_weights(c_void_p(_dev(w, "w")), Cout, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())),
-          "glass_winograd_pack_weights")
+    fn = L.glass_winograd43_pack_weights if f43 else L.glass_winograd_pack_weights
+    check(fn(c_void_p(_dev(w, "w")), Cout, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())),
+          "glass_winograd43_pack_weights" if f43 else "glass_winograd_pack_weights")
     return u
 
 
-def _winograd_weights(w: torch.Tensor) -> torch.Tensor:
+def _use_f43(N: int, H: int, W: int, Cout: int) -> bool:
+    """F(4x4,3x3) pays when the 4x4 tiling does not waste much of the map (H, W rounded up to multiples of 4 vs 2)
+    and the grid still fills the chip (16 tiles x 128 channels per workgroup)."""
+    t4 = ((H + 3) // 4) * ((W + 3) // 4)
+    waste = (t4 * 16.0) / (((H + 1) // 2) * ((W + 1) // 2) * 4.0)
+    blocks = ((N * t4 + 15) // 16) * (Cout // 128)
+    return waste <= 1.25 and blocks >= 192
+
+
+def _winograd_weights(w: torch.Tensor, f43: bool = False) -> torch.Tensor:
     cache = _WINO["cache"]
-    key = (w.data_ptr(), tuple(w.shape))
+    key = (w.data_ptr(), tuple(w.shape), f43)
     ent = cache.get(key)
     if ent is not None and ent[0] is w and ent[2] == w._version:
         cache.move_to_end(key)
         return ent[1]
-    u = winograd_pack(w)
+    u = winograd_pack(w, f43)
     torch.cuda.current_stream().synchronize()      # once per weight: other streams (pipelined steps) may use it next
     cache[key] = (w, u, w._version)
     if len(cache) > _WINO["max"]:
@@ -142,7 +163,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                 cin: Optional[int] = None, winograd: Optional[bool] = None) -> torch.Tensor:
     """y = act(conv(x, w) + bias [+ residual]).  x [N,H,W,ldx] NHWC, w [Cout,KH,KW,Cin].
     3x3/stride 1/pad 1 layers that glass_winograd_supported() accepts go through the Winograd kernel
-    (winograd=None: follow set_winograd(); True/False force it for this call)."""
+    (winograd=None: follow set_winograd() / set_winograd43(); True/False force F(2x2,3x3) on / off for this call,
+    "f43" forces the F(4x4,3x3) kernel)."""
     _f32c(x, "x"); _f32c(w, "w")
     N, H, W, ldx = x.shape
     Cout, KH, KW, Cin = w.shape
@@ -180,6 +202,18 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         # the Winograd kernel runs one 64-tile x 64-channel workgroup per CU: below ~96 workgroups (FPN p6, batch-2 res5)
         # the direct kernel's smaller tiles fill the chip better (measured 0.68-0.82x vs 1.15x at 128 workgroups)
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
+    f43 = winograd == "f43" or (winograd is None and _WINO["f43"] and use_wino and KH == 3 and _use_f43(N, H, W, Cout))
+    if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
+        u = _winograd_weights(w, True)
+        _WINO["last_path"] = "winograd43"
+        check(lib().glass_conv3x3_winograd43_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
+                                                  c_void_p(_dev(bias, "bias") if bias is not None else None),
+                                                  c_void_p(_dev(residual, "residual") if residual is not None else None),
+                                                  c_void_p(_dev(out, "out")), c_void_p(stream_handle())),
+              "glass_conv3x3_winograd43_nhwc")
+        return out
+    if winograd == "f43":
+        raise GlassLibraryError("winograd='f43' but glass_winograd43_supported() rejects this layer")
     if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
         u = _winograd_weights(w)
         _WINO["last_path"] = "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd"

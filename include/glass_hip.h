@@ -96,6 +96,20 @@ int glass_winograd_pack_weights(const float* w, int Cout, int Cin, float* u_pack
 int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                 const float* residual, float* y, glass_stream_t stream);
 
+/* Winograd F(4x4,3x3) form (csrc/winograd43.hip): 36 multiplies per 4x4 output tile = 1.78x fewer than F(2x2,3x3),
+ * 4x fewer than the direct convolution, for the layers with Cout % 128 == 0 and Cin % 32 == 0 (the 128/256/512
+ * channel 3x3 layers: FPN outputs, RPN head, trunk, local extractor layer2..4, mask head).  Transform points
+ * (0, 1, -1, 1/2, -2, inf): results equal glass_conv2d_nhwc to <= 2e-5 of the output range (fp64 reference;
+ * tests/test_gpu_ops.py), still two orders of magnitude inside the path's 1e-3 bar.  Same descriptor, epilogue
+ * semantics and error behaviour as glass_conv3x3_winograd_nhwc; its own packed weight layout (36 * Cout * Cin
+ * floats).  glass_winograd43_supported additionally wants input, output and residual spans < 1 GiB each (split
+ * 32-bit offsets) - callers fall back to the F(2x2) entry.                                                        */
+int glass_winograd43_supported(const glass_conv_desc* d);
+size_t glass_winograd43_weight_floats(int Cout, int Cin);
+int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream);
+int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
+                                  const float* residual, float* y, glass_stream_t stream);
+
 /* max pooling NHWC (d2 stem max_pool2d k3 s2 p1; local extractor maxpool1..3,
  * glass/modeling/fusion/local_feature_extraction.py:112,118,124). Padding acts as -inf. */
 int glass_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,

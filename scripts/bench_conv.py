@@ -65,6 +65,14 @@ for name, N, H, W, Cin, Cout, k, s, p in LAYERS:
         msw = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y2, winograd=True))
         err = float((y2 - y).abs().max() / y.abs().max())
         line += f" | winograd {msw:8.3f} ms {flops / msw / 1e9:7.1f} TFLOP/s-equivalent  x{ms / msw:.2f}  rel.err {err:.1e}"
+    if k == 3 and K.lib().glass_winograd43_supported(K.ctypes.byref(d)):
+        y4 = torch.empty_like(y)
+        ms4 = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y4, winograd="f43"))
+        err = float((y4 - y).abs().max() / y.abs().max())
+        line += f" | F(4x4) {ms4:8.3f} ms {flops / ms4 / 1e9:7.1f} TF/s-eq  x{ms / ms4:.2f}  rel.err {err:.1e}"
+    if os.environ.get("BENCH_CONV_NO_FP16"):
+        print(line, flush=True)
+        continue
     K.set_conv_precision("fp16")
     y3 = torch.empty_like(y)
     msh = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y3))

@@ -93,6 +93,85 @@ def test_winograd_matches_direct_and_torch(case):
     assert float((got_w - got_d).abs().max()) <= 2e-5 * scale
 
 
+WINO43_CASES = [
+    # N, H, W, Cin, Cout, relu, residual, (ld_out, coff)
+    (1, 4, 4, 32, 128, 0, False, None),           # a single tile, a single k-tile
+    (3, 16, 33, 256, 256, 1, True, None),         # local extractor layer3 shape: width 33 -> 9 tile columns, 3 ragged
+    (2, 15, 21, 64, 128, 2, True, None),          # odd height and width, ReLU before the residual add
+    (1, 64, 64, 128, 128, 1, False, None),
+    (5, 8, 32, 512, 256, 0, False, (512, 256)),   # fusion output conv writing into a wider buffer
+    (2, 7, 5, 32, 384, 1, True, None),            # three channel blocks, tiny image (tiles mostly padding)
+    (2, 9, 11, 96, 256, 1, True, None),           # 3 k-tiles, ragged last tile block
+    (1, 31, 40, 64, 384, 0, False, (512, 128)),   # three channel blocks into a wider buffer at an offset
+    (2, 1, 3, 32, 128, 1, False, None),           # smaller than one tile
+]
+
+
+@pytest.mark.parametrize("case", WINO43_CASES)
+def test_winograd43_matches_direct_and_torch(case):
+    """glass_conv3x3_winograd43_nhwc (F(4x4,3x3), points 0, 1, -1, 1/2, -2, inf) vs torch CPU fp64 and vs the direct kernel.
+    Tolerance: 2e-5 of the output range (the kernel's documented bound; measured values are printed)."""
+    from glass_amd.ops import native as K
+    N, H, W, Cin, Cout, relu, use_res, strided = case
+    dev = _dev()
+    x = _rand((N, Cin, H, W), 11)
+    w = _rand((Cout, Cin, 3, 3), 12, (2.0 / (Cin * 9)) ** 0.5)
+    b = _rand((Cout,), 13, 0.1)
+    res = _rand((N, Cout, H, W), 14) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu == 2:
+        ref = F.relu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    if relu == 1:
+        ref = F.relu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
+    kw = dict(padding=1, relu=relu, residual=rd, res_mode=1 if rd is not None else 0)
+    if strided is None:
+        yw = K.conv2d_nhwc(xd, wd, b.to(dev), winograd="f43", **kw)
+        assert K.last_conv_path() == "winograd43"
+        yd = K.conv2d_nhwc(xd, wd, b.to(dev), winograd=False, **kw)
+    else:
+        ld, coff = strided
+        bufw = torch.full((N, H, W, ld), 7.0, device=dev)
+        bufd = torch.full((N, H, W, ld), 7.0, device=dev)
+        K.conv2d_nhwc(xd, wd, b.to(dev), winograd="f43", out=bufw, out_coff=coff, **kw)
+        K.conv2d_nhwc(xd, wd, b.to(dev), winograd=False, out=bufd, out_coff=coff, **kw)
+        torch.cuda.synchronize()
+        assert float((bufw[..., :coff] - 7.0).abs().max()) == 0.0      # untouched channels stay untouched
+        assert float((bufw[..., coff + Cout:] - 7.0).abs().max()) == 0.0 if coff + Cout < ld else True
+        yw, yd = bufw[..., coff:coff + Cout], bufd[..., coff:coff + Cout]
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    got_w = yw.cpu().permute(0, 3, 1, 2).double()
+    got_d = yd.cpu().permute(0, 3, 1, 2).double()
+    ew, ed = float((got_w - ref).abs().max()) / scale, float((got_d - ref).abs().max()) / scale
+    print(f"F(4x4,3x3) {case[:5]}: max err / range = {ew:.2e} (direct kernel {ed:.2e})")
+    assert ew <= 2e-5
+    assert float((got_w - got_d).abs().max()) <= 2e-5 * scale
+
+
+def test_winograd43_on_post_relu_activations_with_a_mean():
+    """F(4x4,3x3) error depends on the INPUT's magnitude, not the output's: non-negative (post-ReLU) inputs with a
+    large mean are the unfavourable case of the real network.  256 channels, inputs relu(N(1,1)): still <= 2e-5 of range."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    x = torch.relu(_rand((2, 256, 32, 32), 21) + 1.0)
+    w = _rand((256, 256, 3, 3), 22, (2.0 / (256 * 9)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    y = K.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), None, padding=1,
+                      winograd="f43")
+    y2 = K.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), None, padding=1,
+                       winograd=True)
+    scale = float(ref.abs().max())
+    e4 = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max()) / scale
+    e2 = float((y2.cpu().permute(0, 3, 1, 2).double() - ref).abs().max()) / scale
+    print(f"post-ReLU inputs, 256 ch: F(4x4) err/range {e4:.2e}, F(2x2) {e2:.2e}")
+    assert e4 <= 2e-5
+
+
 def test_winograd_rejects_unsupported():
     from glass_amd.ops import native as K
     from glass_amd._lib import GlassLibraryError
