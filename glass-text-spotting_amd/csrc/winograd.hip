@@ -611,7 +611,7 @@ extern "C" int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float
                   "glass_conv3x3_winograd_nhwc: pointers must be 16-byte aligned");
   if (d->N == 0) return GLASS_OK;
   WinoParams p;
-  p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y;
+  p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y; p.dbg = nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
   p.TH = (d->H + 1) / 2; p.TW = (d->W + 1) / 2;
   const long nt = (long)d->N * p.TH * p.TW;

@@ -27,6 +27,7 @@
 //     writes + ~390 VALU, all metered between the MFMAs (the source order IS the issue order, pinned with
 //     sched_barrier like the F(2x2) kernels); V is double buffered, one barrier per k-tile.
 #include "wino_common.h"
+#include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -39,6 +40,7 @@ constexpr int N4 = 128;                       // output channels per block
 constexpr int K4 = 32;                        // input channels per k-tile
 constexpr int V4_FLOATS = 36 * T4 * K4;       // 72 KiB per stage
 constexpr int WINO43_LDS_BYTES = 2 * V4_FLOATS * 4;
+constexpr int RING = 4;                       // weight-fragment ring slots (groups in flight = RING - 1)
 constexpr unsigned INV = 0x40000000u;         // "invalid" part of a split offset: any sum containing it is >= 1 GiB
 
 __device__ __forceinline__ float comp4(const f32x4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
@@ -70,6 +72,7 @@ __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, floa
   y3 = __builtin_fmaf(-8.f, m4, __builtin_fmaf(0.125f, m3, d)) + m5;
 }
 
+template <int ABL>   // timing ablations (GLASS_W43_ABL): 0 = product, 1 = weights from one hot chunk, 2 = no transform VALU, 3 = no patch loads
 __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // XCD-aware tile map (see conv.hip): cout-blocks innermost so the blocks that share an input patch sit on one L2
@@ -83,6 +86,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tpi = p.TH * p.TW;
+  unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
+  if constexpr (ABL == 4) stamp0 = __builtin_amdgcn_s_memtime();
 
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
@@ -112,6 +117,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   float dx[36], dy[36];                       // the two channels of the 6x6 patch, transformed in place
   auto load_patch1 = [&](int kt, auto i_) {
     constexpr int i = decltype(i_)::value;
+    if constexpr (ABL == 3) { if (kt > 1) return; }
     // (bit_cast the whole vector: __builtin_bit_cast of a single vector ELEMENT reads element 0 with this compiler)
     const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, rowoff[i / 6] + coloff[i % 6], kt * (K4 * 4), 0));
     dx[i] = v.x;
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   // (which write V[i][*] to LDS as they go)
   auto row_step = [&](auto c_, auto s_) {
     constexpr int c = decltype(c_)::value, S = decltype(s_)::value;
+    if constexpr (ABL == 2) return;
     bx.template step<S>(dx[0 + c], dx[6 + c], dx[12 + c], dx[18 + c], dx[24 + c], dx[30 + c]);
     by.template step<S>(dy[0 + c], dy[6 + c], dy[12 + c], dy[18 + c], dy[24 + c], dy[30 + c]);
     if constexpr (S == 5) {
@@ -138,6 +145,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   };
   auto col_step = [&](int stage, auto i_, auto s_) {
     constexpr int i = decltype(i_)::value, S = decltype(s_)::value;
+    if constexpr (ABL == 2) {
+      if constexpr (S == 1) vstore(stage, i * 6 + 0, dx[i * 6 + 0], dy[i * 6 + 0]);
+      if constexpr (S == 2) vstore(stage, i * 6 + 1, dx[i * 6 + 1], dy[i * 6 + 1]);
+      if constexpr (S == 3) vstore(stage, i * 6 + 2, dx[i * 6 + 2], dy[i * 6 + 2]);
+      if constexpr (S == 4) vstore(stage, i * 6 + 5, dx[i * 6 + 5], dy[i * 6 + 5]);
+      if constexpr (S == 5) { vstore(stage, i * 6 + 3, dx[i * 6 + 3], dy[i * 6 + 3]); vstore(stage, i * 6 + 4, dx[i * 6 + 4], dy[i * 6 + 4]); }
+      return;
+    }
     bx.template step<S>(dx[i * 6 + 0], dx[i * 6 + 1], dx[i * 6 + 2], dx[i * 6 + 3], dx[i * 6 + 4], dx[i * 6 + 5]);
     by.template step<S>(dy[i * 6 + 0], dy[i * 6 + 1], dy[i * 6 + 2], dy[i * 6 + 3], dy[i * 6 + 4], dy[i * 6 + 5]);
     if constexpr (S == 1) vstore(stage, i * 6 + 0, bx.o0, by.o0);
@@ -160,12 +175,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   const int vswz = (vj >> 1) & 7;
   const float* vb[2] = {smem + vj * K4 + ((0 * 4 + kg) ^ vswz) * 4, smem + vj * K4 + ((1 * 4 + kg) ^ vswz) * 4};
   const unsigned a_voff = (unsigned)lane * 16u;
-  f32x4 aq[4][2];                             // weight fragments: [ring slot = group & 3][cb]
+  f32x4 aq[RING][2];                          // weight fragments: [ring slot = group % RING][cb]
   f32x4 vq[2];                                // V fragments: [group & 1]
   // packed U: [tile_n][kt][xi][wave][half][cb] chunks of 1 KiB (64 lanes x float4); group u = 2 xi + half
   auto load_a1 = [&](int kt, int u, int cb) {
-    const int base = ((((tile_n * p.nk + kt) * 36 + (u >> 1)) * 4 + wv) * 4 + (u & 1) * 2 + cb) * 1024;
-    aq[u & 3][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, base, 0));
+    const int base = ABL == 1 ? ((u & 1) * 2 + cb) * 1024 : ((((tile_n * p.nk + kt) * 36 + (u >> 1)) * 4 + wv) * 4 + (u & 1) * 2 + cb) * 1024;
+    aq[u % RING][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, base, 0));
   };
   auto read_v = [&](int stage, int u) {
     vq[u & 1] = *reinterpret_cast<const f32x4*>(vb[u & 1] + stage * V4_FLOATS + (u >> 1) * (T4 * K4));
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   // ---- prologue: patch 0 -> V[0], weight fragments of the first three groups, patch 1 in flight ----
   static_for<36>([&](auto i_) { load_patch1(0, i_); });
 #pragma unroll
-  for (int u = 0; u < 3; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
+  for (int u = 0; u < RING - 1; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
   static_for<6>([&](auto c_) { static_for<6>([&](auto s_) { row_step(c_, s_); }); });
   static_for<6>([&](auto i_) { static_for<6>([&](auto s_) { col_step(0, i_, s_); }); });
   {
@@ -182,6 +197,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     static_for<36>([&](auto i_) { load_patch1(k1, i_); });
   }
   __syncthreads();
+  if constexpr (ABL == 4) stamp1 = __builtin_amdgcn_s_memtime();
 
   for (int kt = 0; kt < p.nk; ++kt) {
     const int cur = kt & 1;
@@ -196,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
         constexpr int s = m >> 1, cb = m & 1;
         // side work issued BEFORE MFMA (u, m)
         if constexpr (m == 0 || m == 2) {                 // weight fragments of the group three ahead
-          constexpr int u3 = u + 3;
+          constexpr int u3 = u + RING - 1;
           if constexpr (u3 < 72) load_a1(kt, u3, m >> 1); else load_a1(ktn, u3 - 72, m >> 1);
           __builtin_amdgcn_sched_barrier(0);
         } else if constexpr (m == 4) {
@@ -213,13 +229,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        acc[xi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(aq[u & 3][cb], s), comp4(vq[u & 1], s), acc[xi][cb], 0, 0, 0);
+        acc[xi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(aq[u % RING][cb], s), comp4(vq[u & 1], s), acc[xi][cb], 0, 0, 0);
       });
       __builtin_amdgcn_sched_barrier(0);
     });
     __syncthreads();     // V[cur] fully read, V[cur^1] fully written
   }
 
+  if constexpr (ABL == 4) stamp2 = __builtin_amdgcn_s_memtime();
   // ---- epilogue: Y = At M A in registers; lane = (tile vj, channels n0 + 32 wv + 8 kg + 4 cb + e) ----
   // 32-bit buffer addressing with split offsets (row part + column part; an invalid part = 2^30 makes the sum out of
   // range): a pixel that does not exist (ragged last tile block, H or W not a multiple of 4) loads zeros / drops the store.
@@ -289,6 +306,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
         v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yrow[a] + ycol[b], cb * 16, 0);
       }
+  }
+  if constexpr (ABL == 4) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+    if (p.dbg != nullptr && tid == 0) {
+      unsigned long long* o = p.dbg + (long)blockIdx.x * 4;
+      o[0] = stamp0; o[1] = stamp1; o[2] = stamp2; o[3] = stamp3;
+    }
   }
 }
 
@@ -362,7 +387,7 @@ extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const flo
                   "glass_conv3x3_winograd43_nhwc: pointers must be 16-byte aligned");
   if (d->N == 0) return GLASS_OK;
   WinoParams p;
-  p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y;
+  p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y; p.dbg = nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
   p.TH = (d->H + 3) / 4; p.TW = (d->W + 3) / 4;
   const long nt = (long)d->N * p.TH * p.TW;
@@ -380,13 +405,40 @@ extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const flo
   p.r_bytes = d->res_mode == 1 ? (unsigned)((long)d->N * d->H * d->W * d->ldr * 4) : 0u;
   const long nblk = (long)p.tiles_m * p.tiles_n;
   GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv3x3_winograd43_nhwc: bad grid");
-  static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino43_f32),
+  static const int abl = getenv("GLASS_W43_ABL") ? atoi(getenv("GLASS_W43_ABL")) : 0;      // timing ablations (wrong results)
+  auto kern = abl == 1 ? conv3x3_wino43_f32<1> : abl == 2 ? conv3x3_wino43_f32<2> : abl == 3 ? conv3x3_wino43_f32<3>
+            : abl == 4 ? conv3x3_wino43_f32<4> : conv3x3_wino43_f32<0>;
+  static unsigned long long* dbg_dev = nullptr;
+  if (abl == 4) {
+    if (!dbg_dev) (void)hipMalloc(&dbg_dev, 4L * 8 * 65536);
+    p.dbg = nblk <= 65536 ? dbg_dev : nullptr;
+  }
+  static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WINO43_LDS_BYTES);
   if (attr_rc != 0) {
     glass_set_error("glass_conv3x3_winograd43_nhwc: cannot reserve %d bytes of LDS (hip error %d)", WINO43_LDS_BYTES, attr_rc);
     return GLASS_EHIP;
   }
-  hipLaunchKernelGGL(conv3x3_wino43_f32, dim3((unsigned)nblk), dim3(256), WINO43_LDS_BYTES, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), WINO43_LDS_BYTES, (hipStream_t)stream, p);
   GLASS_CHECK_LAUNCH("glass_conv3x3_winograd43_nhwc");
+  if (abl == 4 && p.dbg) {      // instrumented build: print the phase times of a few workgroups (drains the stream)
+    static int printed = 0;
+    if (printed++ < 4) {
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      std::vector<unsigned long long> h(4 * nblk);
+      (void)hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost);
+      unsigned long long t_min = ~0ull, t_max = 0;
+      double pro = 0, loop = 0, epi = 0;
+      for (long b = 0; b < nblk; ++b) {
+        t_min = h[4 * b] < t_min ? h[4 * b] : t_min; t_max = h[4 * b + 3] > t_max ? h[4 * b + 3] : t_max;
+        pro += (double)(h[4 * b + 1] - h[4 * b]); loop += (double)(h[4 * b + 2] - h[4 * b + 1]); epi += (double)(h[4 * b + 3] - h[4 * b + 2]);
+      }
+      fprintf(stderr, "[w43 dbg] blocks %ld nk %d: mean cycles prologue %.0f  k-loop %.0f (%.0f / k-tile)  epilogue %.0f | kernel span %llu (s_memtime ticks)\n",
+              nblk, p.nk, pro / nblk, loop / nblk, loop / nblk / p.nk, epi / nblk, t_max - t_min);
+      for (long b = 0; b < 3 && b < nblk; ++b)
+        fprintf(stderr, "[w43 dbg]   block %ld: start %llu  +%llu  +%llu  +%llu\n", b, h[4 * b] - t_min, h[4 * b + 1] - h[4 * b],
+                h[4 * b + 2] - h[4 * b + 1], h[4 * b + 3] - h[4 * b + 2]);
+    }
+  }
   return GLASS_OK;
 }
