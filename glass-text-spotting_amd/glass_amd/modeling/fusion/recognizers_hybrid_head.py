@@ -219,16 +219,26 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
                         override_boxes: Optional[List[torch.Tensor]] = None) -> BatchedDetections:
         return drive(self.forward_batched_g(img_nhwc4, feats, prop_boxes, prop_counts, image_sizes, override_boxes))
 
-    def forward_batched_g(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor,
-                          prop_counts: torch.Tensor, image_sizes: List[Tuple[int, int]],
-                          override_boxes: Optional[List[torch.Tensor]] = None):
-        """Generator form (utils/pipeline.py): yields a ReadBack where the host needs the detection counts."""
-        device = prop_boxes.device
-        hw = K.upload(image_sizes, torch.int32, device)
-        ob, os_, oi, orient2, oc = self.box_branch_batched(feats, prop_boxes, prop_counts, hw)
+    def box_branch_detections(self, feats, prop_boxes, prop_counts, image_hw_dev):
+        """box branch + the orientation rows of the kept detections: device tensors only, static shapes (the part of
+        the ROI head that the meta-arch captures into its hipGraph)."""
+        ob, os_, oi, orient2, oc = self.box_branch_batched(feats, prop_boxes, prop_counts, image_hw_dev)
         orient = None
         if orient2 is not None:
             orient = torch.gather(orient2, 1, oi.long().unsqueeze(-1).expand(-1, -1, 2))
+        return ob, os_, oi, orient, oc
+
+    def forward_batched_g(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], prop_boxes: torch.Tensor,
+                          prop_counts: torch.Tensor, image_sizes: List[Tuple[int, int]],
+                          override_boxes: Optional[List[torch.Tensor]] = None, box_out=None):
+        """Generator form (utils/pipeline.py): yields a ReadBack where the host needs the detection counts.
+        `box_out`: (boxes, scores, kept index, orientations, counts) when the caller already ran the box branch."""
+        device = prop_boxes.device
+        if box_out is None:
+            hw = K.upload(image_sizes, torch.int32, device)
+            box_out = self.box_branch_detections(feats, prop_boxes, prop_counts, hw)
+        ob, os_, oi, orient, oc = box_out
+        orient2 = orient
         counts = (yield ReadBack(oc))[0].tolist()     # host read-back: per-image detection counts size the recognizer batch
         det = BatchedDetections(ob, os_, orient, oc, counts, image_sizes)
         det.kept_index = oi

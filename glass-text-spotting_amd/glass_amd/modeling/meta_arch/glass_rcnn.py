@@ -69,12 +69,14 @@ class GeneralizedRCNN(InferenceModule):
         return self.load_state_dict(load_checkpoint_file(path))
 
     # ------------------------------------------------------------------ pipeline
-    def preprocess_image(self, batched_inputs: List[Dict]) -> ImageList:
-        """normalise + zero-pad to a multiple of 32 into one NHWC4 batch (glass_rcnn.py:82)."""
+    def preprocess_image(self, batched_inputs: List[Dict], into: Optional[torch.Tensor] = None) -> ImageList:
+        """normalise + zero-pad to a multiple of 32 into one NHWC4 batch (glass_rcnn.py:82).  `into`: an existing
+        [N,Hp,Wp,4] buffer to fill (the static input of a captured graph)."""
         imgs = [x["image"] for x in batched_inputs]
         sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in imgs]
         Hp, Wp = ImageList.padded_shape(sizes, self.backbone.size_divisibility)
-        batch = torch.empty((len(imgs), Hp, Wp, 4), dtype=torch.float32, device=self._device)
+        batch = into if into is not None else torch.empty((len(imgs), Hp, Wp, 4), dtype=torch.float32, device=self._device)
+        assert tuple(batch.shape) == (len(imgs), Hp, Wp, 4)
         for n, im in enumerate(imgs):
             im = im.to(self._device)
             if im.dtype != torch.float32:
@@ -105,22 +107,39 @@ class GeneralizedRCNN(InferenceModule):
             self._inference_body_g(batched_inputs, detected_instances, do_postprocess, override_boxes),
             lambda: K.set_conv_precision(self.conv_precision), K.set_conv_precision))
 
+    def _trunk(self, nhwc4: torch.Tensor, hw: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """padded batch -> FPN features, RPN proposals and the box head's detections: every shape here follows from
+        (N, Hp, Wp) alone and nothing reads back to the host (scripts/exp_hipgraph_trunk.py captures exactly this function
+        into a hipGraph: on ROCm 7.2 the replay is 3-7 % SLOWER than the ~100 stream launches it replaces - DESIGN.md)."""
+        feats = self.backbone.forward_nhwc(nhwc4)
+        rpn_in = [feats[f] for f in self.proposal_generator.in_features]
+        pboxes, plogits, pcounts = self.proposal_generator.forward_batched(rpn_in, hw)
+        ob, os_, oi, orient, oc = self.roi_heads.box_branch_detections(feats, pboxes, pcounts, hw)
+        out = {"pboxes": pboxes, "plogits": plogits, "pcounts": pcounts, "ob": ob, "os": os_, "oi": oi, "oc": oc}
+        if orient is not None:
+            out["orient"] = orient
+        out.update({"feat." + k: v for k, v in feats.items()})
+        return out
+
     def _inference_body_g(self, batched_inputs, detected_instances, do_postprocess, override_boxes):
-        images = self.preprocess_image(batched_inputs)
-        feats = self.backbone.forward_nhwc(images.nhwc4)
         if detected_instances is None:
-            hw = K.upload(images.image_sizes, torch.int32, self._device)
-            rpn_in = [feats[f] for f in self.proposal_generator.in_features]
-            pboxes, _plogits, pcounts = self.proposal_generator.forward_batched(rpn_in, hw)
-            det = yield from self.roi_heads.forward_batched_g(images.nhwc4, feats, pboxes, pcounts, images.image_sizes,
-                                                              override_boxes=override_boxes)
-            det.proposals = (pboxes, _plogits, pcounts)      # padded RPN output of this step (parity tests, debugging)
+            sizes = [(int(x["image"].shape[-2]), int(x["image"].shape[-1])) for x in batched_inputs]
+            hw_new = K.upload(sizes, torch.int32, self._device)
+            images = self.preprocess_image(batched_inputs)
+            t = self._trunk(images.nhwc4, hw_new)
+            feats = {k[5:]: v for k, v in t.items() if k.startswith("feat.")}
+            det = yield from self.roi_heads.forward_batched_g(
+                images.nhwc4, feats, t["pboxes"], t["pcounts"], images.image_sizes, override_boxes=override_boxes,
+                box_out=(t["ob"], t["os"], t["oi"], t.get("orient"), t["oc"]))
+            det.proposals = (t["pboxes"], t["plogits"], t["pcounts"])      # padded RPN output of this step (parity tests)
             if do_postprocess:
                 return (yield from self._postprocess_batched_g(det, batched_inputs, images.image_sizes))
             self.last_batch = det                # convenience for the synchronous API only; pipelined callers use .batch
             out = StepOutput(det.to_instances())
             out.batch = det
             return out
+        images = self.preprocess_image(batched_inputs)
+        feats = self.backbone.forward_nhwc(images.nhwc4)
         detected_instances = [x.to(self._device) for x in detected_instances]
         results = self.roi_heads._recognize_into(images.nhwc4, feats, detected_instances)
         if do_postprocess:
