@@ -81,3 +81,9 @@ class ResNetFeatureExtractor(InferenceModule):
         if x.shape[-1] == 3:
             x = torch.nn.functional.pad(x, (0, 1))
         return self.forward_nhwc(x.contiguous()).permute(0, 3, 1, 2)
+
+
+# reference local_feature_extraction.py:33-42: its constructor calls `super(ResNet_FeatureExtractorV2, self)` - a name that
+# does not exist (NameError) - so no reference config can select it either
+LOCAL_FEATURE_EXTRACTOR_REGISTRY.register_unbuilt(
+    "ResNetFeatureExtractorV2", "its reference constructor raises NameError (local_feature_extraction.py:36), no config uses it")

@@ -108,7 +108,12 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         rc = cfg.MODEL.ROI_RECOGNIZER_HEAD
         self.recognizer_in_features = list(rc.IN_FEATURES)
         assert rc.POOLER_TYPE in ["ROIAlignRotated"], rc.POOLER_TYPE
-        assert not rc.RECOGNIZER_HEAD.POOLER_PAD.NAME, "POOLER_PAD is not built (empty in all reference configs)"
+        if rc.RECOGNIZER_HEAD.POOLER_PAD.NAME:
+            # reference recognizer_pooler_pad.py:28-95 (FeatPadV2): pads AXIS-ALIGNED pooled boxes (it indexes x1,y1,x2,y2);
+            # the GLASS head pools rotated boxes and every shipped config leaves the name empty
+            raise NotImplementedError(
+                f"POOLER_PAD.NAME={rc.RECOGNIZER_HEAD.POOLER_PAD.NAME!r}: FeatPadV2 (reference recognizer_pooler_pad.py:28-95) is "
+                "written for axis-aligned boxes and is unusable with the rotated pooler of this head; not built")
         assert len(self.recognizer_in_features) == 2, "recognizer expects [p2, p3] (all reference configs)"
         self.rec_ph, self.rec_pw = rc.POOLER_RESOLUTION_HEIGHT, rc.POOLER_RESOLUTION_WIDTH
         self.rec_scale = 1.0 / input_shape[self.recognizer_in_features[0]].stride

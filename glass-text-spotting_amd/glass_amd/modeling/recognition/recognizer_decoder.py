@@ -54,6 +54,12 @@ class ASTER_V2(InferenceModule):
             "temperature": float(sd[q + "temperature"].reshape(-1)[0]) if (q + "temperature") in sd else 1.0,
         }
 
+    def beam_search(self, x, beam_width, eos):
+        """reference prediction_aster.py:101-222: never called on the inference path (`forward` -> `sample`, :63-99,
+        greedy) nor by any tool of the reference; not built."""
+        raise NotImplementedError("AttentionRecognitionHead.beam_search (reference prediction_aster.py:101-222) is dead code in the "
+                                  "reference's inference path (greedy `sample` is what runs); this build implements `sample` only")
+
     def forward(self, features: torch.Tensor, labels=None, roi_image: Optional[torch.Tensor] = None,
                 num_images: int = 1) -> torch.Tensor:
         """features [R,T,D] -> probabilities [R,max_word_len,num_classes].  `roi_image` (int32 [R],

@@ -12,10 +12,21 @@ from __future__ import annotations
 from typing import Any, Dict, Iterator, Optional, Tuple
 
 
+class _Unbuilt:
+    """placeholder of a reference name this build knows about but does not implement"""
+    def __init__(self, reason: str) -> None:
+        self.reason = reason
+
+
 class Registry:
     def __init__(self, name: str) -> None:
         self._name = name
         self._obj_map: Dict[str, Any] = {}
+
+    def register_unbuilt(self, name: str, reason: str) -> None:
+        """A name the reference registers that this build deliberately does not implement: `get(name)` raises
+        NotImplementedError with the reason instead of the KeyError of an unknown name."""
+        self._do_register(name, _Unbuilt(reason))
 
     def _do_register(self, name: str, obj: Any) -> None:
         if name in self._obj_map:
@@ -36,13 +47,15 @@ class Registry:
         ret = self._obj_map.get(name)
         if ret is None:
             raise KeyError(f"No object named '{name}' found in '{self._name}' registry!")
+        if isinstance(ret, _Unbuilt):
+            raise NotImplementedError(f"'{name}' ({self._name} registry) is a reference name this build does not implement: {ret.reason}")
         return ret
 
     def __contains__(self, name: str) -> bool:
         return name in self._obj_map
 
     def __iter__(self) -> Iterator[Tuple[str, Any]]:
-        return iter(self._obj_map.items())
+        return iter((k, v) for k, v in self._obj_map.items() if not isinstance(v, _Unbuilt))
 
     def keys(self):
         return self._obj_map.keys()

@@ -10,9 +10,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _cfg():
+def _cfg(opts=()):
     from glass_amd.config import get_glass_cfg
-    return get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", "cpu"])
+    return get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", "cpu"] + list(opts))
 
 
 def test_config_own_yaml_and_overrides():
@@ -260,3 +260,52 @@ def test_upload_helper_cpu_semantics():
     assert t.dtype == torch.int32 and t.tolist() == [[3, 4], [5, 6]] and t.device.type == "cpu"
     u = K.upload(torch.tensor([1.5, 2.5]), torch.float32, torch.device("cpu"))
     assert u.tolist() == [1.5, 2.5]
+
+
+def test_unbuilt_reference_names_fail_with_a_reason_not_a_keyerror():
+    """f4 leftovers: names the reference registers but this build does not implement say so explicitly."""
+    import glass_amd  # noqa: F401
+    from glass_amd.modeling.fusion.local_feature_extraction import LOCAL_FEATURE_EXTRACTOR_REGISTRY
+    from glass_amd.modeling.recognition.recognizer_decoder import ASTER_V2
+    from glass_amd.structures.core import ShapeSpec
+    with pytest.raises(NotImplementedError, match="NameError"):
+        LOCAL_FEATURE_EXTRACTOR_REGISTRY.get("ResNetFeatureExtractorV2")
+    assert "ResNetFeatureExtractorV2" not in dict(iter(LOCAL_FEATURE_EXTRACTOR_REGISTRY))
+    with pytest.raises(KeyError):
+        LOCAL_FEATURE_EXTRACTOR_REGISTRY.get("NoSuchExtractor")
+    dec = ASTER_V2(_cfg(), ShapeSpec(channels=256))
+    with pytest.raises(NotImplementedError, match="beam_search"):
+        dec.beam_search(None, 5, 1)
+    cfg = _cfg(["MODEL.ROI_RECOGNIZER_HEAD.RECOGNIZER_HEAD.POOLER_PAD.NAME", "FeatPadV2"])
+    with pytest.raises(NotImplementedError, match="axis-aligned"):
+        glass_amd.build_model(cfg)
+
+
+def test_mirror_into_detectron2_registers_our_classes(monkeypatch):
+    """utils.registry.mirror_into_detectron2() with a stand-in `detectron2.modeling` (detectron2 itself is not
+    installable here): every meta-arch / proposal generator / ROI head of ours lands in d2's registries under the
+    reference's names, existing d2 entries are left alone, and without detectron2 the call is a no-op returning False."""
+    import sys
+    import types
+    import glass_amd  # noqa: F401
+    from glass_amd.utils import registry as R
+    for k in [k for k in sys.modules if k == "detectron2" or k.startswith("detectron2.")]:
+        monkeypatch.delitem(sys.modules, k)
+    monkeypatch.setitem(sys.modules, "detectron2", None)                 # import detectron2 -> ImportError
+    assert R.mirror_into_detectron2() is False
+    d2 = types.ModuleType("detectron2")
+    mod = types.ModuleType("detectron2.modeling")
+    sentinel = object()
+    mod.META_ARCH_REGISTRY = R.Registry("META_ARCH")
+    mod.META_ARCH_REGISTRY.register(sentinel, name="GeneralizedRCNN")     # d2's own class must survive
+    mod.PROPOSAL_GENERATOR_REGISTRY = R.Registry("PROPOSAL_GENERATOR")
+    mod.ROI_HEADS_REGISTRY = R.Registry("ROI_HEADS")
+    d2.modeling = mod
+    monkeypatch.setitem(sys.modules, "detectron2", d2)
+    monkeypatch.setitem(sys.modules, "detectron2.modeling", mod)
+    assert R.mirror_into_detectron2() is True
+    assert mod.META_ARCH_REGISTRY.get("GlassRCNN") is R.META_ARCH_REGISTRY.get("GlassRCNN")
+    assert mod.META_ARCH_REGISTRY.get("GeneralizedRCNN") is sentinel
+    assert mod.PROPOSAL_GENERATOR_REGISTRY.get("RotatedRPN") is R.PROPOSAL_GENERATOR_REGISTRY.get("RotatedRPN")
+    assert mod.ROI_HEADS_REGISTRY.get("MaskRotatedRecognizerHybridHead") is R.ROI_HEADS_REGISTRY.get("MaskRotatedRecognizerHybridHead")
+    assert R.mirror_into_detectron2() is True                             # idempotent
