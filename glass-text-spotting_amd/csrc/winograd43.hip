@@ -35,11 +35,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int T4 = 16;                        // output tiles (4x4 pixels each) per block
-constexpr int N4 = 128;                       // output channels per block
-constexpr int K4 = 32;                        // input channels per k-tile
-constexpr int V4_FLOATS = 36 * T4 * K4;       // 72 KiB per stage
-constexpr int WINO43_LDS_BYTES = 2 * V4_FLOATS * 4;
+// Two shapes of the same kernel (template parameters WT x WC = how the 4 waves split the block, KT = k-tile):
+//   wide   WT = 1, WC = 4, KT = 32:  16 tiles x 128 channels  (Cout % 128 == 0, Cin % 32 == 0: the 128..512-channel layers)
+//   narrow WT = 2, WC = 2, KT = 16:  32 tiles x  64 channels  (Cout %  64 == 0, Cin % 16 == 0: the 64-channel layers; two
+//          waves share every weight fragment through the L1, V keeps its 72 KiB per stage with half the channels)
+constexpr int WINO43_LDS_BYTES = 2 * 36 * 16 * 32 * 4;      // V: 2 stages x 36 xi x (16 WT tiles) x KT channels = 144 KiB for both shapes
 constexpr int RING = 4;                       // weight-fragment ring slots (groups in flight = RING - 1)
 constexpr unsigned INV = 0x40000000u;         // "invalid" part of a split offset: any sum containing it is >= 1 GiB
 
@@ -72,8 +72,19 @@ __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, floa
   y3 = __builtin_fmaf(-8.f, m4, __builtin_fmaf(0.125f, m3, d)) + m5;
 }
 
-template <int ABL>   // timing ablations (GLASS_W43_ABL): 0 = product, 1 = weights from one hot chunk, 2 = no transform VALU, 3 = no patch loads
+template <int ABL, int WT, int WC, int KT>   // ABL: timing ablations (GLASS_W43_ABL): 0 = product, 1 = weights from one hot chunk, 2 = no transform VALU, 3 = no patch loads, 4 = phase stamps
 __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
+  static_assert(WT * WC == 4 && (KT == 32 || KT == 16) && 16 * WT * (KT / 2) == 256, "4 waves; one (tile, channel pair) per thread");
+  constexpr int T4 = 16 * WT;                 // output tiles (4x4 pixels each) per block
+  constexpr int N4 = 32 * WC;                 // output channels per block
+  constexpr int K4 = KT;                      // input channels per k-tile
+  constexpr int V4_FLOATS = 36 * T4 * K4;     // 72 KiB per stage
+  constexpr int HALVES = KT / 16;             // 16-channel halves of a k-tile: one ds_read_b128 + 4 MFMA k-steps each
+  constexpr int NG = 36 * HALVES;             // MFMA groups (xi, half) per k-tile, 8 MFMAs each
+  constexpr int SPG = 144 / NG;               // transform / load micro-steps per group (108 steps per k-tile)
+  constexpr int SLOTS = KT / 4;               // 16-byte slots per V row
+  constexpr int RPW = 64 / KT;                // V rows per 256 bytes (one wrap of the 64 banks)
+  static_assert(NG % RING == 0, "ring slot = group % RING must be consistent across k-tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // XCD-aware tile map (see conv.hip): cout-blocks innermost so the blocks that share an input patch sit on one L2
   const int nblk = gridDim.x, bid = blockIdx.x;
@@ -92,8 +103,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
 
-  // ---- input role: thread = (tile tl, channel pair c2 of the 32) ----
-  const int c2 = tid & 15, tl = tid >> 4;
+  // ---- input role: thread = (tile tl, channel pair c2 of the k-tile) ----
+  const int c2 = tid % (KT / 2), tl = tid / (KT / 2);
+  const int wc = WC == 4 ? wv : (wv & (WC - 1)), wt = WC == 4 ? 0 : (wv / WC);
   unsigned rowoff[6], coloff[6];
   {
     const int t = t0 + tl;
@@ -123,9 +135,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     dx[i] = v.x;
     dy[i] = v.y;
   };
-  // V[stage][xi][tile][32]: a row is 128 bytes = half of the 64 banks, consecutive tiles alternate halves; the 16-byte
-  // slot is XOR-ed with (tile/2)%8 so that the 16 tiles a ds_read_b128 service group touches hit 16 different slots.
-  float* vdst = smem + tl * K4 + (((c2 >> 1) ^ ((tl >> 1) & 7)) * 4) + (c2 & 1) * 2;
+  // V[stage][xi][tile][KT]: a row is 128 (64) bytes = a half (quarter) of the 64 banks; the 16-byte slot is XOR-ed with
+  // (tile / rows-per-256-bytes) % slots so that the 16 tiles a ds_read_b128 service group touches hit 16 different slots.
+  float* vdst = smem + tl * K4 + (((c2 >> 1) ^ ((tl / RPW) % SLOTS)) * 4) + (c2 & 1) * 2;
   Bt6 bx, by;
   // transform micro-steps (compile-time index): 36 row steps (column c, step S), then per row i six column steps
   // (which write V[i][*] to LDS as they go)
@@ -162,8 +174,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     if constexpr (S == 5) { vstore(stage, i * 6 + 3, bx.o3, by.o3); vstore(stage, i * 6 + 4, bx.o4, by.o4); }
   };
 
-  // ---- MFMA role: wave wv owns channels n0 + 32 wv + [0, 32) for all 36 xi ----
-  // 16x16x4: A[i = lane&15][k = lane>>4] = weights (row i = 4 g' + e  <->  channel 32 wv + 8 g' + 4 cb + e),
+  // ---- MFMA role: wave (wt, wc) owns tiles 16 wt + [0, 16) x channels n0 + 32 wc + [0, 32) for all 36 xi ----
+  // 16x16x4: A[i = lane&15][k = lane>>4] = weights (row i = 4 g' + e  <->  channel 32 wc + 8 g' + 4 cb + e),
   //          B[k = lane>>4][j = lane&15] = V (tile j);  C/D: lane holds rows 4 (lane>>4) + e, column lane&15.
   f32x4 acc[36][2];
 #pragma unroll
@@ -172,18 +184,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     for (int cb = 0; cb < 2; ++cb) acc[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int vj = lane & 15, kg = lane >> 4;
-  const int vswz = (vj >> 1) & 7;
-  const float* vb[2] = {smem + vj * K4 + ((0 * 4 + kg) ^ vswz) * 4, smem + vj * K4 + ((1 * 4 + kg) ^ vswz) * 4};
+  const int vt = 16 * wt + vj;                // this lane's tile within the block
+  const int vswz = (vt / RPW) % SLOTS;
+  const float* vb[2] = {smem + vt * K4 + ((0 * 4 + kg) ^ vswz) * 4, smem + vt * K4 + (((HALVES - 1) * 4 + kg) ^ vswz) * 4};
   const unsigned a_voff = (unsigned)lane * 16u;
   f32x4 aq[RING][2];                          // weight fragments: [ring slot = group % RING][cb]
   f32x4 vq[2];                                // V fragments: [group & 1]
-  // packed U: [tile_n][kt][xi][wave][half][cb] chunks of 1 KiB (64 lanes x float4); group u = 2 xi + half
+  // packed U: [tile_n][kt][xi][wc][half][cb] chunks of 1 KiB (64 lanes x float4); group u = HALVES xi + half
   auto load_a1 = [&](int kt, int u, int cb) {
-    const int base = ABL == 1 ? ((u & 1) * 2 + cb) * 1024 : ((((tile_n * p.nk + kt) * 36 + (u >> 1)) * 4 + wv) * 4 + (u & 1) * 2 + cb) * 1024;
+    const int xi = u / HALVES, h = u % HALVES;
+    const int base = ABL == 1 ? (h * 2 + cb) * 1024 : (((((tile_n * p.nk + kt) * 36 + xi) * WC + wc) * HALVES + h) * 2 + cb) * 1024;
     aq[u % RING][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, base, 0));
   };
   auto read_v = [&](int stage, int u) {
-    vq[u & 1] = *reinterpret_cast<const f32x4*>(vb[u & 1] + stage * V4_FLOATS + (u >> 1) * (T4 * K4));
+    vq[u & 1] = *reinterpret_cast<const f32x4*>(vb[u % HALVES] + stage * V4_FLOATS + (u / HALVES) * (T4 * K4));
   };
 
   // ---- prologue: patch 0 -> V[0], weight fragments of the first three groups, patch 1 in flight ----
@@ -204,22 +218,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     const int ktn = kt + 1 < p.nk ? kt + 1 : kt;     // clamped at the end: harmless re-reads keep the loop one block
     const int ktnn = kt + 2 < p.nk ? kt + 2 : kt;
     read_v(cur, 0);
-    static_for<72>([&](auto u_) {
+    static_for<NG>([&](auto u_) {
       constexpr int u = decltype(u_)::value;
-      constexpr int xi = u >> 1;
+      constexpr int xi = u / HALVES;
       static_for<8>([&](auto m_) {
         constexpr int m = decltype(m_)::value;
         constexpr int s = m >> 1, cb = m & 1;
         // side work issued BEFORE MFMA (u, m)
         if constexpr (m == 0 || m == 2) {                 // weight fragments of the group three ahead
           constexpr int u3 = u + RING - 1;
-          if constexpr (u3 < 72) load_a1(kt, u3, m >> 1); else load_a1(ktn, u3 - 72, m >> 1);
+          if constexpr (u3 < NG) load_a1(kt, u3, m >> 1); else load_a1(ktn, u3 - NG, m >> 1);
           __builtin_amdgcn_sched_barrier(0);
         } else if constexpr (m == 4) {
-          if constexpr (u + 1 < 72) { read_v(cur, u + 1); __builtin_amdgcn_sched_barrier(0); }
-        } else if constexpr (m == 1 || m == 5) {
-          constexpr int q = u * 2 + (m == 5 ? 1 : 0);     // 144 slots for the 108 transform / load steps
-          if constexpr (q < 36) {
+          if constexpr (u + 1 < NG) { read_v(cur, u + 1); __builtin_amdgcn_sched_barrier(0); }
+        } else if constexpr (SPG == 2 ? (m == 1 || m == 5) : (m & 1) == 1) {
+          // 144 slots for the 108 transform / load steps; the first 36 stay empty so that the patch loads issued at the
+          // end of the previous k-tile (or by the prologue) have ~4 K cycles to land before the first row step waits on them
+          constexpr int q = (SPG == 2 ? u * 2 + (m == 5 ? 1 : 0) : u * 4 + (m >> 1)) - 36;
+          if constexpr (q < 0) {
+          } else if constexpr (q < 36) {
             row_step(ic<q / 6>{}, ic<q % 6>{});           // Bt d of patch kt+1, column q/6
             __builtin_amdgcn_sched_barrier(0);
           } else if constexpr (q < 108) {
@@ -237,17 +254,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   }
 
   if constexpr (ABL == 4) stamp2 = __builtin_amdgcn_s_memtime();
-  // ---- epilogue: Y = At M A in registers; lane = (tile vj, channels n0 + 32 wv + 8 kg + 4 cb + e) ----
+  // ---- epilogue: Y = At M A in registers; lane = (tile 16 wt + vj, channels n0 + 32 wc + 8 kg + 4 cb + e) ----
   // 32-bit buffer addressing with split offsets (row part + column part; an invalid part = 2^30 makes the sum out of
   // range): a pixel that does not exist (ragged last tile block, H or W not a multiple of 4) loads zeros / drops the store.
   __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_mode == 1 ? p.res : p.y), 0,
                                                                  (int)(p.res_mode == 1 ? p.r_bytes : 0u), 0x00020000);
-  const int cbase = n0 + 32 * wv + 8 * kg;
+  const int cbase = n0 + 32 * wc + 8 * kg;
   const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
   unsigned yrow[4], ycol[4], rrow[4], rcol[4];
   {
-    const int t = t0 + vj;
+    const int t = t0 + vt;
     const bool tv = t < p.ntiles;
     const int n = fast_div(t, tpi, p.magic_tpi);
     const int rem = t - n * tpi;
@@ -269,18 +286,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   }
   // ReLU before (2) / after (1) the residual add as an unconditional max: max(x, qNaN) = x keeps "no ReLU" exact
   const float lo2 = p.relu == 2 ? 0.f : __builtin_nanf(""), lo1 = p.relu == 1 ? 0.f : __builtin_nanf("");
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * cb);
-    f32x4 rres[16];
+  f32x4 rres[2][16];
+  auto load_res = [&](auto cb_) {
+    constexpr int cb = decltype(cb_)::value;
     if (p.res_mode == 1) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          rres[a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 16, 0));
+          rres[cb][a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 16, 0));
     }
+  };
+  load_res(ic<0>{});
+  static_for<2>([&](auto cb_) {
+    constexpr int cb = decltype(cb_)::value;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * cb);
     f32x4 out[16];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -296,17 +317,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
         out[0 * 4 + b][e] = y0; out[1 * 4 + b][e] = y1; out[2 * 4 + b][e] = y2; out[3 * 4 + b][e] = y3;
       }
     }
+    // the other channel block's residual rows are requested as soon as this block's accumulators are dead, a whole
+    // output transform ahead of their use
+    if constexpr (cb == 0) { __builtin_amdgcn_sched_barrier(0); load_res(ic<1>{}); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         f32x4 v = out[a * 4 + b] + bv;
         v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
-        if (p.res_mode == 1) v = v + rres[a * 4 + b];
+        if (p.res_mode == 1) v = v + rres[cb][a * 4 + b];
         v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yrow[a] + ycol[b], cb * 16, 0);
       }
-  }
+  });
   if constexpr (ABL == 4) {
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
@@ -318,11 +342,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
 }
 
 // U = G g G^t (6x6 per channel pair) in the fragment order the kernel streams:
-// [cout/128][cin/32][xi][wave][half][cb][lane][s]   with
-//   cout = 128 tn + 32 wave + 8 ((lane&15)>>2) + 4 cb + (lane&3),   cin = 32 kt + 16 half + 4 (lane>>4) + s
-__global__ void wino43_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
+// [cout/(32 WC)][cin/KT][xi][wc][half][cb][lane][s]   with
+//   cout = 32 WC tn + 32 wc + 8 ((lane&15)>>2) + 4 cb + (lane&3),   cin = KT kt + 16 half + 4 (lane>>4) + s
+__global__ void wino43_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int WC, int KT) {
   const long total = 36L * Cout * Cin;
-  const int nk = Cin / K4;
+  const int nk = Cin / KT, halves = KT / 16;
   const double G[6][3] = {{1.0, 0.0, 0.0}, {1.0 / 3, 1.0 / 3, 1.0 / 3}, {-1.0 / 3, 1.0 / 3, -1.0 / 3},
                           {-16.0 / 15, -8.0 / 15, -4.0 / 15}, {1.0 / 15, -2.0 / 15, 4.0 / 15}, {0.0, 0.0, 1.0}};
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
@@ -330,13 +354,13 @@ __global__ void wino43_pack_weights_kernel(const float* __restrict__ w, float* _
     const int s = (int)(r & 3); r >>= 2;
     const int lane = (int)(r & 63); r >>= 6;
     const int cb = (int)(r & 1); r >>= 1;
-    const int half = (int)(r & 1); r >>= 1;
-    const int wave = (int)(r & 3); r >>= 2;
+    const int half = (int)(r % halves); r /= halves;
+    const int wave = (int)(r % WC); r /= WC;
     const int xi = (int)(r % 36); r /= 36;
     const int kt = (int)(r % nk);
     const int tn = (int)(r / nk);
-    const int co = tn * N4 + 32 * wave + 8 * ((lane & 15) >> 2) + 4 * cb + (lane & 3);
-    const int ci = kt * K4 + 16 * half + 4 * (lane >> 4) + s;
+    const int co = tn * 32 * WC + 32 * wave + 8 * ((lane & 15) >> 2) + 4 * cb + (lane & 3);
+    const int ci = kt * KT + 16 * half + 4 * (lane >> 4) + s;
     const int i = xi / 6, j = xi % 6;
     double acc = 0.0;
 #pragma unroll
@@ -349,13 +373,16 @@ __global__ void wino43_pack_weights_kernel(const float* __restrict__ w, float* _
 
 }  // namespace
 
+// wide shape when the channel counts allow it, else the narrow one (both need Cout % 64 == 0 and Cin % 16 == 0)
+static bool wino43_wide(int Cout, int Cin) { return Cout % 128 == 0 && Cin % 32 == 0; }
+
 extern "C" int glass_winograd43_supported(const glass_conv_desc* d) {
   if (!d) return 0;
   const long xb = (long)d->N * d->H * d->W * d->ldx * 4;
   const long yb = (long)d->N * d->H * d->W * d->ldy * 4, rb = d->res_mode == 1 ? (long)d->N * d->H * d->W * d->ldr * 4 : 0;
   const long lim = 0x40000000L;               // split offsets: every operand below 1 GiB
   return d->KH == 3 && d->KW == 3 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 1 && d->pad_w == 1 &&
-         d->Cin % K4 == 0 && d->Cout % N4 == 0 && d->ldx % 2 == 0 && d->ldx >= d->Cin && d->y_cstride == 1 && d->ldy % 4 == 0 &&
+         d->Cin % 16 == 0 && d->Cout % 64 == 0 && d->ldx % 2 == 0 && d->ldx >= d->Cin && d->y_cstride == 1 && d->ldy % 4 == 0 &&
          d->y_coff % 4 == 0 && d->y_coff >= 0 && d->y_coff + d->Cout <= d->ldy &&
          (d->res_mode == 0 || (d->res_mode == 1 && d->ldr % 4 == 0 && d->ldr >= d->Cout)) && xb < lim && yb < lim && rb < lim &&
          36L * d->Cout * d->Cin * 4 < 0x7fffff00L && d->Ho == d->H && d->Wo == d->W;
@@ -365,11 +392,13 @@ extern "C" size_t glass_winograd43_weight_floats(int Cout, int Cin) { return (si
 
 extern "C" int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream) {
   GLASS_CHECK_ARG(w && u_packed, "glass_winograd43_pack_weights: null pointer");
-  GLASS_CHECK_ARG(Cout > 0 && Cin > 0 && Cout % N4 == 0 && Cin % K4 == 0,
-                  "glass_winograd43_pack_weights: Cout=%d must be a multiple of 128 and Cin=%d a multiple of 32", Cout, Cin);
+  GLASS_CHECK_ARG(Cout > 0 && Cin > 0 && Cout % 64 == 0 && Cin % 16 == 0,
+                  "glass_winograd43_pack_weights: Cout=%d must be a multiple of 64 and Cin=%d a multiple of 16", Cout, Cin);
   const long total = 36L * Cout * Cin;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(wino43_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u_packed, Cout, Cin);
+  const bool wide = wino43_wide(Cout, Cin);
+  hipLaunchKernelGGL(wino43_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, u_packed, Cout, Cin,
+                     wide ? 4 : 2, wide ? 32 : 16);
   GLASS_CHECK_LAUNCH("glass_winograd43_pack_weights");
   return GLASS_OK;
 }
@@ -378,7 +407,7 @@ extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const flo
                                              const float* bias, const float* residual, float* y, glass_stream_t stream) {
   GLASS_CHECK_ARG(d && x && u_packed && y, "glass_conv3x3_winograd43_nhwc: null pointer");
   GLASS_CHECK_ARG(glass_winograd43_supported(d),
-                  "glass_conv3x3_winograd43_nhwc: needs 3x3/stride 1/pad 1, Cin%%32==0, Cout%%128==0, unit channel stride, "
+                  "glass_conv3x3_winograd43_nhwc: needs 3x3/stride 1/pad 1, Cin%%16==0, Cout%%64==0, unit channel stride, "
                   "res_mode 0/1 and operands < 1 GiB (got Cin=%d Cout=%d k=%dx%d s=%d p=%d)", d->Cin, d->Cout, d->KH, d->KW,
                   d->stride_h, d->pad_h);
   GLASS_CHECK_ARG(d->res_mode == 0 || residual != nullptr, "glass_conv3x3_winograd43_nhwc: res_mode set but residual is null");
@@ -393,6 +422,8 @@ extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const flo
   const long nt = (long)d->N * p.TH * p.TW;
   GLASS_CHECK_ARG(nt < 0x7fffffffL, "glass_conv3x3_winograd43_nhwc: too many tiles");
   p.ntiles = (int)nt;
+  const bool wide = wino43_wide(d->Cout, d->Cin);
+  const int T4 = wide ? 16 : 32, N4 = wide ? 128 : 64, K4 = wide ? 32 : 16;
   p.nk = d->Cin / K4;
   p.ldx = d->ldx; p.ldy = d->ldy; p.ycoff = d->y_coff; p.ldr = d->ldr; p.relu = d->relu; p.res_mode = d->res_mode;
   p.tiles_m = cdiv(p.ntiles, T4);
@@ -406,15 +437,21 @@ extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const flo
   const long nblk = (long)p.tiles_m * p.tiles_n;
   GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv3x3_winograd43_nhwc: bad grid");
   static const int abl = getenv("GLASS_W43_ABL") ? atoi(getenv("GLASS_W43_ABL")) : 0;      // timing ablations (wrong results)
-  auto kern = abl == 1 ? conv3x3_wino43_f32<1> : abl == 2 ? conv3x3_wino43_f32<2> : abl == 3 ? conv3x3_wino43_f32<3>
-            : abl == 4 ? conv3x3_wino43_f32<4> : conv3x3_wino43_f32<0>;
+  // (the ablation instantiations 1..3 are compiled only with -DGLASS_W43_ABLATIONS: they triple the build time of this file)
+  auto kern = !wide ? (abl == 4 ? conv3x3_wino43_f32<4, 2, 2, 16> : conv3x3_wino43_f32<0, 2, 2, 16>)
+#ifdef GLASS_W43_ABLATIONS
+            : abl == 1 ? conv3x3_wino43_f32<1, 1, 4, 32> : abl == 2 ? conv3x3_wino43_f32<2, 1, 4, 32> : abl == 3 ? conv3x3_wino43_f32<3, 1, 4, 32>
+#endif
+            : abl == 4 ? conv3x3_wino43_f32<4, 1, 4, 32> : conv3x3_wino43_f32<0, 1, 4, 32>;
   static unsigned long long* dbg_dev = nullptr;
   if (abl == 4) {
     if (!dbg_dev) (void)hipMalloc(&dbg_dev, 4L * 8 * 65536);
     p.dbg = nblk <= 65536 ? dbg_dev : nullptr;
   }
-  static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, WINO43_LDS_BYTES);
+  static int attr_rc_w = -1, attr_rc_n = -1;
+  int& attr_rc = wide ? attr_rc_w : attr_rc_n;
+  if (attr_rc == -1)
+    attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WINO43_LDS_BYTES);
   if (attr_rc != 0) {
     glass_set_error("glass_conv3x3_winograd43_nhwc: cannot reserve %d bytes of LDS (hip error %d)", WINO43_LDS_BYTES, attr_rc);
     return GLASS_EHIP;

@@ -133,12 +133,13 @@ def winograd_pack(w: torch.Tensor, f43: bool = False) -> torch.Tensor:
     return u
 
 
-def _use_f43(N: int, H: int, W: int, Cout: int) -> bool:
+def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int) -> bool:
     """F(4x4,3x3) pays when the 4x4 tiling does not waste much of the map (H, W rounded up to multiples of 4 vs 2)
-    and the grid still fills the chip (16 tiles x 128 channels per workgroup)."""
+    and the grid still fills the chip (16 tiles x 128 channels per workgroup; 32 x 64 for the narrow shape)."""
     t4 = ((H + 3) // 4) * ((W + 3) // 4)
     waste = (t4 * 16.0) / (((H + 1) // 2) * ((W + 1) // 2) * 4.0)
-    blocks = ((N * t4 + 15) // 16) * (Cout // 128)
+    wide = Cout % 128 == 0 and Cin % 32 == 0
+    blocks = ((N * t4 + 15) // 16) * (Cout // 128) if wide else ((N * t4 + 31) // 32) * (Cout // 64)
     return waste <= 1.25 and blocks >= 192
 
 
@@ -202,7 +203,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         # the Winograd kernel runs one 64-tile x 64-channel workgroup per CU: below ~96 workgroups (FPN p6, batch-2 res5)
         # the direct kernel's smaller tiles fill the chip better (measured 0.68-0.82x vs 1.15x at 128 workgroups)
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
-    f43 = winograd == "f43" or (winograd is None and _WINO["f43"] and use_wino and KH == 3 and _use_f43(N, H, W, Cout))
+    f43 = winograd == "f43" or (winograd is None and _WINO["f43"] and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin))
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
         u = _winograd_weights(w, True)
         _WINO["last_path"] = "winograd43"

@@ -104,6 +104,11 @@ WINO43_CASES = [
     (2, 9, 11, 96, 256, 1, True, None),           # 3 k-tiles, ragged last tile block
     (1, 31, 40, 64, 384, 0, False, (512, 128)),   # three channel blocks into a wider buffer at an offset
     (2, 1, 3, 32, 128, 1, False, None),           # smaller than one tile
+    # narrow shape of the kernel (32 tiles x 64 channels, 16-channel k-tiles): the 64-channel layers
+    (2, 16, 16, 64, 64, 1, True, None),           # local extractor layer1 / res2 shape
+    (3, 13, 9, 32, 64, 2, True, None),            # Cin = 32 (two k-tiles), ragged everything
+    (1, 40, 24, 16, 192, 0, False, (256, 64)),    # a single k-tile, three 64-channel blocks into a wider buffer
+    (2, 8, 8, 48, 64, 1, False, None),            # Cin = 48: not a multiple of 32 -> narrow
 ]
 
 
