@@ -8,10 +8,10 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 # 1. kernel trace of the default bench (two steps in flight, two-stream local extractor, as shipped)
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pr_default -o r -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/bench_under_rocprof.log 2>&1
-python scripts/prof_summary.py "$(find /tmp/pr_default -name '*.db' | head -1)" 8 "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras (default: 2 steps in flight, two-stream local extractor)" > gpurun_out/kernel_stats_default.txt
+python scripts/prof_summary.py "$(find /tmp/pr_default -name '*.db' | head -1)" 0 "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras (default: 2 steps in flight, two-stream local extractor)" > gpurun_out/kernel_stats_default.txt
 # 2. the same, one step at a time on a single stream (per-kernel durations comparable with bench.py's serial metering step)
 GLASS_SINGLE_STREAM=1 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/pr_serial -o r -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --pipeline 1 > gpurun_out/bench_under_rocprof_serial.log 2>&1
-python scripts/prof_summary.py "$(find /tmp/pr_serial -name '*.db' | head -1)" 8 "GLASS_SINGLE_STREAM=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --pipeline 1 (one step at a time, one stream)" > gpurun_out/kernel_stats_serial.txt
+python scripts/prof_summary.py "$(find /tmp/pr_serial -name '*.db' | head -1)" 0 "GLASS_SINGLE_STREAM=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --pipeline 1 (one step at a time, one stream)" > gpurun_out/kernel_stats_serial.txt
 # 3. PMC passes (counters only, own runs)
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $c | cut -d' ' -f1)

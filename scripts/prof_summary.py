@@ -8,6 +8,9 @@ import sys
 db = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 c = sqlite3.connect(db)
+n_pp = c.execute("select count(*) from kernels where name like 'postprocess_words_kernel%'").fetchone()[0]
+if steps <= 0:
+    steps = max(n_pp, 1)            # every bench step ends with one postprocess_words_kernel launch
 rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
                  "from kernels group by name order by 3 desc").fetchall()
 tot = sum(r[2] for r in rows)
@@ -32,7 +35,7 @@ for a, b in zip(ends[:-1], ends[1:]):
     step_lines.append(f"{(b - a) / 1e6:.2f}/{busy / 1e6:.2f}")
 label = sys.argv[3] if len(sys.argv) > 3 else "python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 print(f"# rocprofv3 --kernel-trace --stats summary of: {label}")
-print(f"# source db: {db}; {steps} bench steps in the trace (warmup + timed + 1 metered)")
+print(f"# source db: {db}; {steps} bench steps in the trace (pipeline fill + warmup + timed + 3 metered; = postprocess_words_kernel launches)")
 print(f"# total kernel time {tot / 1e6:.2f} ms  ({tot / 1e6 / steps:.2f} ms per step)")
 print(f"# per step wall/GPU-busy ms (union of kernel intervals between consecutive postprocess_words ends): {' '.join(step_lines)}")
 print(f"{'Name':72s} {'Calls':>7s} {'TotalDurationNs':>16s} {'AverageNs':>12s} {'MinNs':>10s} {'MaxNs':>10s} {'Percentage':>10s}")
