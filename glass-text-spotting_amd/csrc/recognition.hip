@@ -1,12 +1,15 @@
 // Per-RoI recognition kernels: global-to-local fusion attention (softmax pooling + channel MLP),
 // the BiLSTM recurrence and the greedy attention-GRU decoder.
 //
-// All three are independent across RoIs, so a workgroup owns a small group of RoIs for the
-// whole sequence (persistent over the T / max_len dependent steps: no launch per step and no
-// host sync), keeps the recurrent state in LDS, and streams the recurrent weights from L2 in
-// a k-blocked layout (packed[k/4][row][4]) so that the 64 lanes of a wavefront read 1 KiB
-// contiguous per load.  Reductions (softmax, LayerNorm, attention energies) are wavefront
-// shuffle reductions (64 lanes) + one LDS hop across the 4 wavefronts.
+// All three are independent across RoIs.  The fusion attention is one workgroup per RoI.  The two recurrences are
+// ONE LAUNCH PER DEPENDENT STEP (T launches of lstm_step_kernel per layer; dec_fc_att_kernel + dec_gru_kernel per
+// decoding step), all issued by a single ABI call with no host synchronisation - the arg-max feedback and the
+// recurrent state stay on the device (state double-buffered in a global workspace, previous rows staged in LDS).
+// A persistent workgroup per RoI group (no launch per step) was the first design and lost: it has to pull the whole
+// 1 MiB recurrent matrix through ONE CU per step (27 us per step measured vs 8 us with each step spread over the chip
+// on 16x16x4 fp32 MFMA tiles).  Weights stream from L2 in a k-blocked layout
+// (packed[k/4][row][4]) so that the 64 lanes of a wavefront read 1 KiB contiguous per load; reductions (softmax,
+// LayerNorm, attention energies) are wavefront shuffle reductions (64 lanes) + one LDS hop across the 4 wavefronts.
 #include "common.h"
 
 __device__ __forceinline__ float wave_sum(float v) {

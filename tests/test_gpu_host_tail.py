@@ -183,11 +183,15 @@ def test_device_postprocessor_equals_host_restatement_with_text():
         host = pp.host_call(mk())
         devr = pp(mk())
         assert len(host) == len(devr), (case, len(host), len(devr))
-        # chains of merges amplify the 1-ulp sin/cos differences between torch-CPU and the device (fp32 polygons ->
-        # float64 min-area-rect): relative 2e-3 on boxes that went through several merges
-        np.testing.assert_allclose(devr.pred_boxes.tensor.cpu().numpy(), host.pred_boxes.tensor.cpu().numpy(), rtol=2e-3, atol=0.05)
+        # measured (printed above): <= 5e-4 px on coordinates up to 1400 (a few fp32 ulps, from the 1-ulp sin/cos
+        # differences between torch-CPU and the device through chains of merges); asserted at 2e-3 px (round 1: 0.5 px)
+        db = np.abs(devr.pred_boxes.tensor.cpu().numpy() - host.pred_boxes.tensor.cpu().numpy())
+        dp = np.abs(devr.pred_polygons.cpu().numpy() - host.pred_polygons.cpu().numpy())
+        print(f"[post-processor device vs host] case {case}: n = {len(host)}, max |dbox| = {db.max() if db.size else 0:.3e}, "
+              f"max |dpolygon| = {dp.max() if dp.size else 0:.3e} px")
+        np.testing.assert_allclose(devr.pred_boxes.tensor.cpu().numpy(), host.pred_boxes.tensor.cpu().numpy(), rtol=0, atol=2e-3)
         np.testing.assert_allclose(devr.scores.cpu().numpy(), host.scores.cpu().numpy(), atol=1e-6)
-        np.testing.assert_allclose(devr.pred_polygons.cpu().numpy(), host.pred_polygons.cpu().numpy(), rtol=2e-3, atol=0.5)
+        np.testing.assert_allclose(devr.pred_polygons.cpu().numpy(), host.pred_polygons.cpu().numpy(), rtol=0, atol=2e-3)
         assert torch.equal(devr.orientations.cpu(), host.orientations.cpu())
         assert torch.equal(devr.pred_text_prob.cpu(), host.pred_text_prob.cpu())
         from glass_amd.postprocess.post_processor_academic import get_instances_text
