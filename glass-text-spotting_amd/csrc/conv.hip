@@ -556,6 +556,8 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   if (force_cfg == 4) return launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);   // 64 x 64, 8 blocks/CU
   if (force_cfg == 5) return launch_conv_impl<1, 4, 1, 1, 1, 6, 32>(p, s);   // 32 x 128
   if (force_cfg == 6) return launch_conv_impl<4, 1, 1, 3, 1, 4, 32>(p, s);   // 128 x 96
+  if (force_cfg == 7) return launch_conv_impl<2, 2, 4, 2, 1, 2, 32>(p, s);   // 256 x 128, 2 blocks/CU
+  if (force_cfg == 8) return launch_conv_impl<2, 2, 2, 4, 1, 2, 32>(p, s);   // 128 x 256, 2 blocks/CU
   if (d->Cout <= 32) return launch_conv_impl<4, 1, 1, 1, 1, 4, 32>(p, s);   // 128 x 32
   if (d->Cout <= 64) return launch_conv_impl<2, 2, 2, 1, 1, 4, 32>(p, s);   // 128 x 64
   if (d->Cout <= 96) return launch_conv_impl<4, 1, 1, 3, 1, 4, 32>(p, s);   // 128 x 96 (the merged 72-channel RPN heads: 0.36 -> 0.26 ms)

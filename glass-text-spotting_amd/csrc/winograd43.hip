@@ -61,6 +61,23 @@ struct Bt6 {
   }
 };
 
+// the same on a channel PAIR (packed fp32: v_pk_fma_f32 / v_pk_add_f32 process both channels in one issue slot; beside
+// the f32 MFMA, which occupies the vector ALU, halving the transform's instruction count is what counts)
+struct Bt6p {
+  f32x2 a, b, o0, o1, o2, o3, o4, o5;
+  static __device__ __forceinline__ f32x2 fma2(float c, f32x2 x, f32x2 y) {
+    return __builtin_elementwise_fma(f32x2{c, c}, x, y);
+  }
+  template <int S> __device__ __forceinline__ void step(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5) {
+    if constexpr (S == 0) { a = d3 - d1; b = d4 - d2; }
+    if constexpr (S == 1) o0 = fma2(-2.f, d2, fma2(1.5f, a, d0 + d4));
+    if constexpr (S == 2) o1 = fma2(2.5f, d3, fma2(0.5f, d2, d4 - d1));
+    if constexpr (S == 3) o2 = fma2(0.5f, d3, fma2(-2.5f, d2, d4 + d1));
+    if constexpr (S == 4) o5 = fma2(-2.f, d3, fma2(1.5f, b, d1 + d5));
+    if constexpr (S == 5) { o3 = fma2(2.f, a, b); o4 = fma2(-0.5f, a, b); }
+  }
+};
+
 // four-point output transform (rows of At): y0 = m0+m1+m2+m3+m4, y1 = m1-m2+m3/2-2m4, y2 = m1+m2+m3/4+4m4,
 // y3 = m1-m2+m3/8-8m4+m5
 __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1,
@@ -126,52 +143,46 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
       coloff[c] = ((unsigned)wi < (unsigned)p.W) ? (unsigned)((wi * p.ldx + 2 * c2) * 4) : INV;
     }
   }
-  float dx[36], dy[36];                       // the two channels of the 6x6 patch, transformed in place
+  f32x2 dd[36];                               // the channel pair of the 6x6 patch, transformed in place
   auto load_patch1 = [&](int kt, auto i_) {
     constexpr int i = decltype(i_)::value;
     if constexpr (ABL == 3) { if (kt > 1) return; }
     // (bit_cast the whole vector: __builtin_bit_cast of a single vector ELEMENT reads element 0 with this compiler)
-    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, rowoff[i / 6] + coloff[i % 6], kt * (K4 * 4), 0));
-    dx[i] = v.x;
-    dy[i] = v.y;
+    dd[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, rowoff[i / 6] + coloff[i % 6], kt * (K4 * 4), 0));
   };
   // V[stage][xi][tile][KT]: a row is 128 (64) bytes = a half (quarter) of the 64 banks; the 16-byte slot is XOR-ed with
   // (tile / rows-per-256-bytes) % slots so that the 16 tiles a ds_read_b128 service group touches hit 16 different slots.
   float* vdst = smem + tl * K4 + (((c2 >> 1) ^ ((tl / RPW) % SLOTS)) * 4) + (c2 & 1) * 2;
-  Bt6 bx, by;
+  Bt6p bt;
   // transform micro-steps (compile-time index): 36 row steps (column c, step S), then per row i six column steps
   // (which write V[i][*] to LDS as they go)
   auto row_step = [&](auto c_, auto s_) {
     constexpr int c = decltype(c_)::value, S = decltype(s_)::value;
     if constexpr (ABL == 2) return;
-    bx.template step<S>(dx[0 + c], dx[6 + c], dx[12 + c], dx[18 + c], dx[24 + c], dx[30 + c]);
-    by.template step<S>(dy[0 + c], dy[6 + c], dy[12 + c], dy[18 + c], dy[24 + c], dy[30 + c]);
+    bt.template step<S>(dd[0 + c], dd[6 + c], dd[12 + c], dd[18 + c], dd[24 + c], dd[30 + c]);
     if constexpr (S == 5) {
-      dx[0 + c] = bx.o0; dx[6 + c] = bx.o1; dx[12 + c] = bx.o2; dx[18 + c] = bx.o3; dx[24 + c] = bx.o4; dx[30 + c] = bx.o5;
-      dy[0 + c] = by.o0; dy[6 + c] = by.o1; dy[12 + c] = by.o2; dy[18 + c] = by.o3; dy[24 + c] = by.o4; dy[30 + c] = by.o5;
+      dd[0 + c] = bt.o0; dd[6 + c] = bt.o1; dd[12 + c] = bt.o2; dd[18 + c] = bt.o3; dd[24 + c] = bt.o4; dd[30 + c] = bt.o5;
     }
   };
-  auto vstore = [&](int stage, int xi, float vx, float vy) {
-    f32x2 v; v.x = vx; v.y = vy;
+  auto vstore = [&](int stage, int xi, f32x2 v) {
     *reinterpret_cast<f32x2*>(vdst + stage * V4_FLOATS + xi * (T4 * K4)) = v;
   };
   auto col_step = [&](int stage, auto i_, auto s_) {
     constexpr int i = decltype(i_)::value, S = decltype(s_)::value;
     if constexpr (ABL == 2) {
-      if constexpr (S == 1) vstore(stage, i * 6 + 0, dx[i * 6 + 0], dy[i * 6 + 0]);
-      if constexpr (S == 2) vstore(stage, i * 6 + 1, dx[i * 6 + 1], dy[i * 6 + 1]);
-      if constexpr (S == 3) vstore(stage, i * 6 + 2, dx[i * 6 + 2], dy[i * 6 + 2]);
-      if constexpr (S == 4) vstore(stage, i * 6 + 5, dx[i * 6 + 5], dy[i * 6 + 5]);
-      if constexpr (S == 5) { vstore(stage, i * 6 + 3, dx[i * 6 + 3], dy[i * 6 + 3]); vstore(stage, i * 6 + 4, dx[i * 6 + 4], dy[i * 6 + 4]); }
+      if constexpr (S == 1) vstore(stage, i * 6 + 0, dd[i * 6 + 0]);
+      if constexpr (S == 2) vstore(stage, i * 6 + 1, dd[i * 6 + 1]);
+      if constexpr (S == 3) vstore(stage, i * 6 + 2, dd[i * 6 + 2]);
+      if constexpr (S == 4) vstore(stage, i * 6 + 5, dd[i * 6 + 5]);
+      if constexpr (S == 5) { vstore(stage, i * 6 + 3, dd[i * 6 + 3]); vstore(stage, i * 6 + 4, dd[i * 6 + 4]); }
       return;
     }
-    bx.template step<S>(dx[i * 6 + 0], dx[i * 6 + 1], dx[i * 6 + 2], dx[i * 6 + 3], dx[i * 6 + 4], dx[i * 6 + 5]);
-    by.template step<S>(dy[i * 6 + 0], dy[i * 6 + 1], dy[i * 6 + 2], dy[i * 6 + 3], dy[i * 6 + 4], dy[i * 6 + 5]);
-    if constexpr (S == 1) vstore(stage, i * 6 + 0, bx.o0, by.o0);
-    if constexpr (S == 2) vstore(stage, i * 6 + 1, bx.o1, by.o1);
-    if constexpr (S == 3) vstore(stage, i * 6 + 2, bx.o2, by.o2);
-    if constexpr (S == 4) vstore(stage, i * 6 + 5, bx.o5, by.o5);
-    if constexpr (S == 5) { vstore(stage, i * 6 + 3, bx.o3, by.o3); vstore(stage, i * 6 + 4, bx.o4, by.o4); }
+    bt.template step<S>(dd[i * 6 + 0], dd[i * 6 + 1], dd[i * 6 + 2], dd[i * 6 + 3], dd[i * 6 + 4], dd[i * 6 + 5]);
+    if constexpr (S == 1) vstore(stage, i * 6 + 0, bt.o0);
+    if constexpr (S == 2) vstore(stage, i * 6 + 1, bt.o1);
+    if constexpr (S == 3) vstore(stage, i * 6 + 2, bt.o2);
+    if constexpr (S == 4) vstore(stage, i * 6 + 5, bt.o5);
+    if constexpr (S == 5) { vstore(stage, i * 6 + 3, bt.o3); vstore(stage, i * 6 + 4, bt.o4); }
   };
 
   // ---- MFMA role: wave (wt, wc) owns tiles 16 wt + [0, 16) x channels n0 + 32 wc + [0, 32) for all 36 xi ----
