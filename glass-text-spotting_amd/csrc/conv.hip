@@ -36,6 +36,7 @@ struct ConvParams {
   unsigned y_bytes, r_bytes;      // output / residual spans of the vector epilogue (it is enabled only if they fit 31 bits)
   unsigned magic_cin, magic_kw;   // floor(2^32 / Cin), floor(2^32 / KW) for the per-thread tap decode (MODE 2)
   int half_mode;                  // 1: fp16 operands on v_mfma_f32_32x32x16_f16 (glass_conv2d_nhwc_f16)
+  int xh, yh, rh;                 // half_mode only (glass_conv2d_nhwc_h16): x / y / residual are fp16 tensors in HBM
 };
 
 __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
@@ -45,6 +46,7 @@ __device__ __forceinline__ float4 sel4(bool ok, float4 v) {
 
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // MODE 0: plain loads, 64-bit addresses (tensors >= 2 GiB).  MODE 1 ("FAST"): Cin % 32 == 0, buffer loads, uniform
 // scalar tap tracking.  MODE 2: any Cin % 4 == 0 (stem, Cin = 4 / 16 first layers), buffer loads, per-thread tap decode
@@ -141,6 +143,17 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     for (int i = 0; i < B_LOADS; ++i) b_voff[i] = b_ok[i] ? (unsigned)(b_off[i] * 4) : OOB;
   }
 
+  // 4 consecutive input channels at fp32 byte offset `off` (OOB -> zeros).  fp16 storage (half_mode, p.xh): the same 4
+  // channels are 8 bytes at half the offset; they are widened here and rounded back (exactly) when the tile is staged.
+  auto load_x4 = [&](unsigned off) -> float4 {
+    if constexpr (HALF) {
+      if (p.xh) {
+        const h4 v = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(xr, off == OOB ? OOB : off >> 1, 0, 0));
+        return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+      }
+    }
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+  };
   auto load_tile_fast = [&](int kt) {
     const int koff = ((f_dh * p.W + f_dw) * p.ldx + f_c0) * 4;                         // uniform, bytes
 #pragma unroll
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
       const int hi = a_hi0[i] + f_dh, wi = a_wi0[i] + f_dw;
       const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
       const unsigned off = ok ? (unsigned)(a_off[i] + koff) : OOB;
-      areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+      areg[i] = load_x4(off);
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
       const int hi = a_hi0[i] + dh, wi = a_wi0[i] + dw;
       const bool ok = kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
       const unsigned off = ok ? (unsigned)(a_off[i] + koff) : OOB;
-      areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+      areg[i] = load_x4(off);
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i)
@@ -376,7 +389,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
           const int wo = rem - ho * p.Wo;
           roff = (unsigned)(n * HoWo2 + (ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * ldr4 + (unsigned)co * 4u;
         }
-        rres[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? roff : EOOB, 0, 0));
+        if (HALF && p.rh) {
+          const h4 hv = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rr, ok ? roff >> 1 : EOOB, 0, 0));
+          rres[it] = make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+        } else {
+          rres[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? roff : EOOB, 0, 0));
+        }
       }
     };
 #pragma unroll
@@ -414,8 +432,14 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
           v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr,
-                                               ok ? ybase + (unsigned)(it * RPI) * ldy4 : EOOB, 0, 0);
+        if (HALF && p.yh) {
+          const h4 hv = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};          // v_cvt_f16_f32: RNE
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), yr,
+                                                ok ? (ybase + (unsigned)(it * RPI) * ldy4) >> 1 : EOOB, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr,
+                                                 ok ? ybase + (unsigned)(it * RPI) * ldy4 : EOOB, 0, 0);
+        }
       }
     }
     return;
@@ -435,17 +459,21 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
         if (cok && m < p.M) {
           float v = acc[i][j][e] + bv;
           if (p.relu == 2) v = fmaxf(v, 0.f);
+          const _Float16* resh = reinterpret_cast<const _Float16*>(p.res);
+          const bool rh = HALF && p.rh;
           if (p.res_mode == 1) {
-            v += p.res[(long)m * p.ldr + co];
+            v += rh ? (float)resh[(long)m * p.ldr + co] : p.res[(long)m * p.ldr + co];
           } else if (p.res_mode == 2) {
             const int n = m / HoWo;
             const int rem = m - n * HoWo;
             const int ho = rem / p.Wo;
             const int wo = rem - ho * p.Wo;
-            v += p.res[((long)n * HoWo2 + (long)(ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * p.ldr + co];
+            const long ri = ((long)n * HoWo2 + (long)(ho >> 1) * (p.Wo >> 1) + (wo >> 1)) * p.ldr + co;
+            v += rh ? (float)resh[ri] : p.res[ri];
           }
           if (p.relu == 1) v = fmaxf(v, 0.f);
-          p.y[(long)m * p.ldy + p.ycoff + (long)co * p.ycs] = v;
+          if (HALF && p.yh) reinterpret_cast<_Float16*>(p.y)[(long)m * p.ldy + p.ycoff + (long)co * p.ycs] = (_Float16)v;
+          else p.y[(long)m * p.ldy + p.ycoff + (long)co * p.ycs] = v;
         }
       }
     }
@@ -484,7 +512,7 @@ static int launch_conv_impl(ConvParams& p, hipStream_t stream) {
 }
 
 static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
-                         float* y, glass_stream_t stream, int half_mode);
+                         float* y, glass_stream_t stream, int half_mode, int h16_flags = 0);
 
 extern "C" int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
                                  const float* residual, float* y, glass_stream_t stream) {
@@ -496,8 +524,15 @@ extern "C" int glass_conv2d_nhwc_f16(const glass_conv_desc* d, const float* x, c
   return conv_dispatch(d, x, w, bias, residual, y, stream, 1);
 }
 
+extern "C" int glass_conv2d_nhwc_h16(const glass_conv_desc* d, const void* x, const float* w, const float* bias,
+                                     const void* residual, void* y, int flags, glass_stream_t stream) {
+  GLASS_CHECK_ARG((flags & ~7) == 0, "glass_conv2d_nhwc_h16: unknown flags 0x%x", flags);
+  return conv_dispatch(d, static_cast<const float*>(x), w, bias, static_cast<const float*>(residual), static_cast<float*>(y),
+                       stream, 1, flags);
+}
+
 static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
-                         float* y, glass_stream_t stream, int half_mode) {
+                         float* y, glass_stream_t stream, int half_mode, int h16_flags) {
   GLASS_CHECK_ARG(d && x && w && y, "glass_conv2d_nhwc: null pointer");
   GLASS_CHECK_ARG(d->Cin > 0 && d->Cin % 4 == 0, "glass_conv2d_nhwc: Cin=%d must be a positive multiple of 4", d->Cin);
   GLASS_CHECK_ARG(d->ldx % 4 == 0 && d->ldx >= d->Cin, "glass_conv2d_nhwc: ldx=%d", d->ldx);
@@ -519,6 +554,8 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   if (d->N == 0) return GLASS_OK;
   ConvParams p;
   p.half_mode = half_mode;
+  p.xh = h16_flags & 1; p.yh = (h16_flags >> 1) & 1; p.rh = (h16_flags >> 2) & 1;
+  const long xes = p.xh ? 2 : 4, yes = p.yh ? 2 : 4, res_ = p.rh ? 2 : 4;      // bytes per stored element
   p.x = x; p.w = w; p.bias = bias; p.res = residual; p.y = y;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
   p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w; p.Ho = d->Ho; p.Wo = d->Wo;
@@ -530,9 +567,10 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   p.Ktot = d->KH * d->KW * d->Cin;
   {
     // the buffer-load paths need 31-bit byte offsets (MODE 1 additionally Cin % 32 == 0, checked at launch)
+    // (offsets are computed as fp32 byte offsets and halved for fp16 tensors: the fp32-sized span must fit 31 bits)
     const long xb = (long)d->N * d->H * d->W * d->ldx * 4, wb = (long)d->Cout * p.Ktot * 4;
     const bool small = xb < 0x7fffff00L && wb < 0x7fffff00L;
-    p.x_bytes = small ? (unsigned)xb : 0u;
+    p.x_bytes = small ? (unsigned)(xb / 4 * xes) : 0u;
     p.w_bytes = small ? (unsigned)wb : 0u;
     p.magic_cin = (unsigned)(0x100000000ULL / (unsigned long long)d->Cin);
     p.magic_kw = (unsigned)(0x100000000ULL / (unsigned long long)d->KW);
@@ -545,8 +583,8 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
     const long rb = d->res_mode == 1 ? M * d->ldr * 4
                   : d->res_mode == 2 ? (long)d->N * (d->Ho / 2) * (d->Wo / 2) * d->ldr * 4 : 0;
     if (yb >= 0x7fffff00L || rb >= 0x7fffff00L) p.vec_epi = 0;      // > 2 GiB output: scalar epilogue (64-bit addresses)
-    p.y_bytes = (unsigned)(p.vec_epi ? yb : 0);
-    p.r_bytes = (unsigned)(p.vec_epi ? rb : 0);
+    p.y_bytes = (unsigned)(p.vec_epi ? yb / 4 * yes : 0);
+    p.r_bytes = (unsigned)(p.vec_epi ? rb / 4 * res_ : 0);
   }
   hipStream_t s = (hipStream_t)stream;
   static const int force_cfg = getenv("GLASS_CONV_CFG") ? atoi(getenv("GLASS_CONV_CFG")) : 0;   // tuning aid

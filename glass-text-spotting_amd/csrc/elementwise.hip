@@ -15,8 +15,15 @@ static inline int grid_for(long n, int block) {
 // is the 32-bit (wo, c4) split, and the window loops are compile-time for the shapes the path uses (3x3 / 2x2 /
 // 2x1).  The first version (flat 64-bit index, three 64-bit divisions per output) was VALU-bound at 3x the
 // kernel's HBM time.
-template <int KH, int KW>
-__global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float4* __restrict__ x, float4* __restrict__ y, int H, int W,
+typedef _Float16 mp_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 mp_widen(float4 v) { return v; }
+__device__ __forceinline__ float4 mp_widen(mp_h4 v) { return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+__device__ __forceinline__ void mp_store(float4* p, float4 v) { *p = v; }
+__device__ __forceinline__ void mp_store(mp_h4* p, float4 v) { *p = mp_h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }   // exact: max of fp16 values
+
+// V4 = float4 (fp32 tensors) or mp_h4 (fp16 storage, glass_maxpool2d_nhwc_h16): 4 channels per thread either way
+template <int KH, int KW, typename V4>
+__global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const V4* __restrict__ x, V4* __restrict__ y, int H, int W,
                                                            int C4, int kh_rt, int kw_rt, int sh, int sw, int ph, int pw,
                                                            int Ho, int Wo, int rows) {
   const int kh_n = KH > 0 ? KH : kh_rt, kw_n = KW > 0 ? KW : kw_rt;
@@ -32,42 +39,53 @@ __global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const float4* __restr
     for (int kh = 0; kh < kh_n; ++kh) {
       const int hi = h0 + kh;
       if ((unsigned)hi >= (unsigned)H) continue;
-      const float4* xr = x + ((long)(n * H + hi) * W) * C4 + c4;
+      const V4* xr = x + ((long)(n * H + hi) * W) * C4 + c4;
 #pragma unroll
       for (int kw = 0; kw < kw_n; ++kw) {
         const int wi = w0 + kw;
         if ((unsigned)wi >= (unsigned)W) continue;
-        const float4 v = xr[(long)wi * C4];
+        const float4 v = mp_widen(xr[(long)wi * C4]);
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    y[(long)row * per_row + e] = m;
+    mp_store(&y[(long)row * per_row + e], m);
   }
   }
 }
 
-extern "C" int glass_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,
-                                    int ph, int pw, int Ho, int Wo, glass_stream_t stream) {
-  GLASS_CHECK_ARG(x && y, "glass_maxpool2d_nhwc: null pointer");
-  GLASS_CHECK_ARG(C % 4 == 0 && C > 0, "glass_maxpool2d_nhwc: C=%d must be a multiple of 4", C);
-  GLASS_CHECK_ARG(Ho == (H + 2 * ph - KH) / sh + 1 && Wo == (W + 2 * pw - KW) / sw + 1, "glass_maxpool2d_nhwc: bad Ho/Wo");
+template <typename V4>
+static int maxpool_launch(const void* x, void* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw, int ph, int pw,
+                          int Ho, int Wo, glass_stream_t stream, const char* what) {
+  GLASS_CHECK_ARG(x && y, "%s: null pointer", what);
+  GLASS_CHECK_ARG(C % 4 == 0 && C > 0, "%s: C=%d must be a multiple of 4", what, C);
+  GLASS_CHECK_ARG(Ho == (H + 2 * ph - KH) / sh + 1 && Wo == (W + 2 * pw - KW) / sw + 1, "%s: bad Ho/Wo", what);
   if (N == 0) return GLASS_OK;
   const long rows = (long)N * Ho, per_row = (long)Wo * (C / 4);
-  GLASS_CHECK_ARG(rows <= 0x7fffffffL && per_row <= 0x7fffffffL, "glass_maxpool2d_nhwc: tensor too large");
+  GLASS_CHECK_ARG(rows <= 0x7fffffffL && per_row <= 0x7fffffffL, "%s: tensor too large", what);
   const dim3 grid((unsigned)((per_row + 255) / 256 < 64 ? (per_row + 255) / 256 : 64), (unsigned)(rows < 65535 ? rows : 65535));
-  const float4* x4 = reinterpret_cast<const float4*>(x);
-  float4* y4 = reinterpret_cast<float4*>(y);
+  const V4* x4 = reinterpret_cast<const V4*>(x);
+  V4* y4 = reinterpret_cast<V4*>(y);
   hipStream_t s = (hipStream_t)stream;
   if (KH == 3 && KW == 3)
-    hipLaunchKernelGGL((maxpool_nhwc_kernel<3, 3>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
+    hipLaunchKernelGGL((maxpool_nhwc_kernel<3, 3, V4>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
   else if (KH == 2 && KW == 2)
-    hipLaunchKernelGGL((maxpool_nhwc_kernel<2, 2>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
+    hipLaunchKernelGGL((maxpool_nhwc_kernel<2, 2, V4>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
   else if (KH == 2 && KW == 1)
-    hipLaunchKernelGGL((maxpool_nhwc_kernel<2, 1>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
+    hipLaunchKernelGGL((maxpool_nhwc_kernel<2, 1, V4>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
   else
-    hipLaunchKernelGGL((maxpool_nhwc_kernel<0, 0>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
-  GLASS_CHECK_LAUNCH("glass_maxpool2d_nhwc");
+    hipLaunchKernelGGL((maxpool_nhwc_kernel<0, 0, V4>), grid, dim3(256), 0, s, x4, y4, H, W, C / 4, KH, KW, sh, sw, ph, pw, Ho, Wo, (int)rows);
+  GLASS_CHECK_LAUNCH(what);
   return GLASS_OK;
+}
+
+extern "C" int glass_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,
+                                    int ph, int pw, int Ho, int Wo, glass_stream_t stream) {
+  return maxpool_launch<float4>(x, y, N, H, W, C, KH, KW, sh, sw, ph, pw, Ho, Wo, stream, "glass_maxpool2d_nhwc");
+}
+
+extern "C" int glass_maxpool2d_nhwc_h16(const void* x, void* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,
+                                        int ph, int pw, int Ho, int Wo, glass_stream_t stream) {
+  return maxpool_launch<mp_h4>(x, y, N, H, W, C, KH, KW, sh, sw, ph, pw, Ho, Wo, stream, "glass_maxpool2d_nhwc_h16");
 }
 
 // ---------------------------------------------------------------- preprocess

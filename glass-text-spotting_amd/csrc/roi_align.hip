@@ -19,6 +19,20 @@ struct RoiParams {
   float* out;
 };
 
+typedef _Float16 ra_h4 __attribute__((ext_vector_type(4)));
+// FH: the pyramid levels are fp16 tensors (fp16 storage mode, glass_roi_align_rotated_h16); taps are widened to fp32,
+// the interpolation and the output stay fp32
+template <bool FH>
+__device__ __forceinline__ float4 ra_tap(const float* base, long off) {
+  if constexpr (FH) {
+    const ra_h4 v = *reinterpret_cast<const ra_h4*>(reinterpret_cast<const _Float16*>(base) + off);
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+  } else {
+    return *reinterpret_cast<const float4*>(base + off);
+  }
+}
+
+template <bool FH>
 __global__ __launch_bounds__(256) void roi_align_rotated_kernel(RoiParams p) {
   const long total = (long)p.R * p.PH * p.PW * p.C4;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(256) void roi_align_rotated_kernel(RoiParams p) {
     const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(rw / (float)p.PW);
     const float count = (float)(gh * gw > 1 ? gh * gw : 1);
     const float start_h = -rh / 2.0f, start_w = -rw / 2.0f;
-    const float* base = feat + (long)b * H * W * ld + c4 * 4;
+    const long boff = (long)b * H * W * ld + c4 * 4;          // element offset of (image b, channel group c4) in the level
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int iy = 0; iy < gh; ++iy) {
@@ -76,10 +90,10 @@ __global__ __launch_bounds__(256) void roi_align_rotated_kernel(RoiParams p) {
         if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
         const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
         const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        const float4 v1 = *reinterpret_cast<const float4*>(base + ((long)yl * W + xl) * ld);
-        const float4 v2 = *reinterpret_cast<const float4*>(base + ((long)yl * W + xh) * ld);
-        const float4 v3 = *reinterpret_cast<const float4*>(base + ((long)yh * W + xl) * ld);
-        const float4 v4 = *reinterpret_cast<const float4*>(base + ((long)yh * W + xh) * ld);
+        const float4 v1 = ra_tap<FH>(feat, boff + ((long)yl * W + xl) * ld);
+        const float4 v2 = ra_tap<FH>(feat, boff + ((long)yl * W + xh) * ld);
+        const float4 v3 = ra_tap<FH>(feat, boff + ((long)yh * W + xl) * ld);
+        const float4 v4 = ra_tap<FH>(feat, boff + ((long)yh * W + xh) * ld);
         // same association order as the reference CPU op: w1*v1 + w2*v2 + w3*v3 + w4*v4
         acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
         acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
@@ -97,8 +111,8 @@ __global__ __launch_bounds__(256) void roi_align_rotated_kernel(RoiParams p) {
   }
 }
 
-extern "C" int glass_roi_align_rotated(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R,
-                                       float* out, glass_stream_t stream) {
+static int roi_align_launch(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R, float* out,
+                            glass_stream_t stream, bool feat_half) {
   GLASS_CHECK_ARG(d && out, "glass_roi_align_rotated: null pointer");
   GLASS_CHECK_ARG(d->num_levels >= 1 && d->num_levels <= 5, "glass_roi_align_rotated: num_levels=%d", d->num_levels);
   GLASS_CHECK_ARG(d->C > 0 && d->C % 4 == 0, "glass_roi_align_rotated: C=%d must be a multiple of 4", d->C);
@@ -118,7 +132,20 @@ extern "C" int glass_roi_align_rotated(const glass_roialign_desc* d, const float
   const long total = (long)R * p.PH * p.PW * p.C4;
   long g = (total + 255) / 256;
   if (g > 256L * 32) g = 256L * 32;
-  hipLaunchKernelGGL(roi_align_rotated_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+  if (feat_half)
+    hipLaunchKernelGGL(roi_align_rotated_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(roi_align_rotated_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
   GLASS_CHECK_LAUNCH("glass_roi_align_rotated");
   return GLASS_OK;
+}
+
+extern "C" int glass_roi_align_rotated(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R,
+                                       float* out, glass_stream_t stream) {
+  return roi_align_launch(d, boxes, batch_idx, R, out, stream, false);
+}
+
+extern "C" int glass_roi_align_rotated_h16(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R,
+                                           float* out, glass_stream_t stream) {
+  return roi_align_launch(d, boxes, batch_idx, R, out, stream, true);
 }

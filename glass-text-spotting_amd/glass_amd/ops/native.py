@@ -48,6 +48,13 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+def _fhc(t: torch.Tensor, name: str) -> torch.Tensor:
+    """contiguous float32 or float16 (fp16 storage mode) activation tensor"""
+    if t.dtype not in (torch.float32, torch.float16) or not t.is_contiguous():
+        raise GlassLibraryError(f"{name} must be contiguous float32 / float16 (got {t.dtype}, contiguous={t.is_contiguous()})")
+    return t
+
+
 def upload(data, dtype: torch.dtype, device) -> torch.Tensor:
     """A few host integers / floats -> device tensor WITHOUT draining the stream.  `torch.tensor(data, device=...)` and
     `.to(device)` of pageable memory are blocking copies: the host waits for everything queued on the stream before it
@@ -83,10 +90,12 @@ _WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": colle
 
 
 def set_conv_precision(precision: str) -> str:
-    """'fp32' (default; the reference's arithmetic, fp32 MFMA / Winograd) or 'fp16' (operands rounded to fp16, fp16 MFMA
-    with fp32 accumulation, direct kernel only - Winograd's transforms are not fp16 safe).  `GLASS_CONV_PRECISION`
-    sets the initial value.  Returns the previous setting."""
-    if precision not in ("fp32", "fp16"):
+    """'fp32' (default; the reference's arithmetic, fp32 MFMA / Winograd), 'fp16' (operands rounded to fp16, fp16 MFMA
+    with fp32 accumulation, direct kernel only - Winograd's transforms are not fp16 safe; activations stay fp32 in HBM)
+    or 'fp16s' (the same arithmetic with the conv-path activations STORED as fp16: the modules ask their entry convs for
+    fp16 outputs, every conv / max-pool / RoIAlign then follows its input's dtype; BASELINE configs[4]).
+    `GLASS_CONV_PRECISION` sets the initial value.  Returns the previous setting."""
+    if precision not in ("fp32", "fp16", "fp16s"):
         raise GlassLibraryError(f"unknown conv precision {precision!r}")
     prev = _WINO["precision"]
     _WINO["precision"] = precision
@@ -95,6 +104,11 @@ def set_conv_precision(precision: str) -> str:
 
 def conv_precision() -> str:
     return _WINO["precision"]
+
+
+def act_dtype() -> torch.dtype:
+    """storage dtype the modules request for conv-path activations: float16 in 'fp16s' mode, else float32"""
+    return torch.float16 if _WINO["precision"] == "fp16s" else torch.float32
 
 
 def last_conv_path() -> str:
@@ -161,12 +175,12 @@ def _winograd_weights(w: torch.Tensor, f43: bool = False) -> torch.Tensor:
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride=1, padding=0,
                 relu: int = 0, residual: Optional[torch.Tensor] = None, res_mode: int = 0,
                 out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cstride: int = 1,
-                cin: Optional[int] = None, winograd: Optional[bool] = None) -> torch.Tensor:
+                cin: Optional[int] = None, winograd: Optional[bool] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """y = act(conv(x, w) + bias [+ residual]).  x [N,H,W,ldx] NHWC, w [Cout,KH,KW,Cin].
     3x3/stride 1/pad 1 layers that glass_winograd_supported() accepts go through the Winograd kernel
     (winograd=None: follow set_winograd() / set_winograd43(); True/False force F(2x2,3x3) on / off for this call,
     "f43" forces the F(4x4,3x3) kernel)."""
-    _f32c(x, "x"); _f32c(w, "w")
+    _fhc(x, "x"); _f32c(w, "w")
     N, H, W, ldx = x.shape
     Cout, KH, KW, Cin = w.shape
     if cin is not None and cin != Cin:
@@ -175,9 +189,10 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     ph, pw = _pair(padding)
     Ho, Wo = conv_out_size(H, W, KH, KW, stride, padding)
     if out is None:
-        out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        # the output follows the input's storage dtype unless told otherwise (fp16 tensors exist only in 'fp16s' mode)
+        out = torch.empty((N, Ho, Wo, Cout), dtype=out_dtype or x.dtype, device=x.device)
     else:
-        _f32c(out, "out")
+        _fhc(out, "out")
         if tuple(out.shape[:3]) != (N, Ho, Wo):
             raise GlassLibraryError(f"out has shape {tuple(out.shape)}, expected ({N},{Ho},{Wo},*)")
     if out_coff < 0 or out_cstride < 1 or out_coff + (Cout - 1) * out_cstride >= out.shape[3]:
@@ -190,8 +205,20 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     d = ConvDesc(N, H, W, Cin, Cout, KH, KW, sh, sw, ph, pw, Ho, Wo, ldx, out.shape[3], out_coff, out_cstride, relu,
                  res_mode if residual is not None else 0, residual.shape[-1] if residual is not None else 0)
     if residual is not None:
-        _f32c(residual, "residual")
-    if _WINO["precision"] == "fp16" and not winograd:
+        _fhc(residual, "residual")
+    any_half = x.dtype == torch.float16 or out.dtype == torch.float16 or (residual is not None and residual.dtype == torch.float16)
+    if any_half:
+        if _WINO["precision"] != "fp16s" or winograd:
+            raise GlassLibraryError("float16 activation tensors need conv precision 'fp16s' (and no forced Winograd)")
+        flags = (1 if x.dtype == torch.float16 else 0) | (2 if out.dtype == torch.float16 else 0) | \
+                (4 if residual is not None and residual.dtype == torch.float16 else 0)
+        _WINO["last_path"] = "direct_fp16"
+        check(lib().glass_conv2d_nhwc_h16(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
+                                          c_void_p(_dev(bias, "bias") if bias is not None else None),
+                                          c_void_p(_dev(residual, "residual") if residual is not None else None),
+                                          c_void_p(_dev(out, "out")), int(flags), c_void_p(stream_handle())), "glass_conv2d_nhwc_h16")
+        return out
+    if _WINO["precision"] in ("fp16", "fp16s") and not winograd:
         _WINO["last_path"] = "direct_fp16"
         check(lib().glass_conv2d_nhwc_f16(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
                                           c_void_p(_dev(bias, "bias") if bias is not None else None),
@@ -235,24 +262,25 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: int = 0,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """x [M,K] @ w[Nout,K]^T + bias on the same MFMA kernel (H = W = KH = KW = 1)."""
     M, K = x.shape
     y = conv2d_nhwc(x.view(M, 1, 1, K), w.view(w.shape[0], 1, 1, K), bias, relu=relu,
-                    out=None if out is None else out.view(M, 1, 1, -1))
+                    out=None if out is None else out.view(M, 1, 1, -1), out_dtype=out_dtype)
     return y.view(M, -1)
 
 
 def maxpool2d_nhwc(x: torch.Tensor, kernel, stride, padding=0) -> torch.Tensor:
-    _f32c(x, "x")
+    _fhc(x, "x")
     N, H, W, C = x.shape
     KH, KW = _pair(kernel)
     sh, sw = _pair(stride)
     ph, pw = _pair(padding)
     Ho, Wo = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
-    y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
-    check(lib().glass_maxpool2d_nhwc(c_void_p(_dev(x)), c_void_p(_dev(y)), N, H, W, C, KH, KW, sh, sw, ph, pw, Ho, Wo,
-                                     c_void_p(stream_handle())), "glass_maxpool2d_nhwc")
+    y = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    fn = lib().glass_maxpool2d_nhwc_h16 if x.dtype == torch.float16 else lib().glass_maxpool2d_nhwc
+    check(fn(c_void_p(_dev(x)), c_void_p(_dev(y)), N, H, W, C, KH, KW, sh, sw, ph, pw, Ho, Wo, c_void_p(stream_handle())),
+          "glass_maxpool2d_nhwc")
     return y
 
 
@@ -332,8 +360,11 @@ def roi_align_rotated(feats: List[torch.Tensor], scales: Sequence[float], boxes:
         out = torch.empty((R, PH, PW, C), dtype=torch.float32, device=feats[0].device)
     d = RoiAlignDesc()
     d.num_levels = len(feats)
+    half = feats[0].dtype == torch.float16
     for i, (f, s) in enumerate(zip(feats, scales)):
-        _f32c(f, f"feat[{i}]")
+        _fhc(f, f"feat[{i}]")
+        if f.dtype != feats[0].dtype:
+            raise GlassLibraryError("all pyramid levels of one RoIAlign call must share a dtype")
         d.feat[i] = _dev(f)
         d.H[i], d.W[i], d.ld[i] = f.shape[1], f.shape[2], f.shape[3]
         d.scale[i] = float(s)
@@ -344,8 +375,9 @@ def roi_align_rotated(feats: List[torch.Tensor], scales: Sequence[float], boxes:
         _f32c(boxes, "boxes")
         if batch_idx.dtype != torch.int32:
             raise GlassLibraryError("batch_idx must be int32")
-        check(lib().glass_roi_align_rotated(ctypes.byref(d), c_void_p(_dev(boxes)), c_void_p(_dev(batch_idx)), R,
-                                            c_void_p(_dev(out)), c_void_p(stream_handle())), "glass_roi_align_rotated")
+        fn = lib().glass_roi_align_rotated_h16 if half else lib().glass_roi_align_rotated
+        check(fn(ctypes.byref(d), c_void_p(_dev(boxes)), c_void_p(_dev(batch_idx)), R, c_void_p(_dev(_f32c(out, "out"))),
+                 c_void_p(stream_handle())), "glass_roi_align_rotated")
     return out
 
 

@@ -71,6 +71,16 @@ int glass_conv2d_nhwc(const glass_conv_desc* d, const float* x, const float* w, 
 int glass_conv2d_nhwc_f16(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
                           const float* residual, float* y, glass_stream_t stream);
 
+/* fp16 STORAGE form of glass_conv2d_nhwc_f16 (BASELINE configs[4]: "fp16"): the same kernel, but the activation tensors
+ * themselves may live in HBM as IEEE fp16 NHWC - flags bit 0: x is fp16, bit 1: y is written as fp16 (round to nearest
+ * even from the fp32 accumulator after bias / ReLU / residual), bit 2: the residual is fp16.  Weights and bias stay fp32
+ * in memory (weights are rounded to fp16 as they are staged, like the operands of the _f16 entry); accumulation is fp32.
+ * ldx / ldy / ldr / y_coff are in ELEMENTS of the respective tensor.  The op equals, bit for bit up to fp32 summation
+ * order, fp16?(act(conv(fp16(x), fp16(w)) + bias [+ residual])) - the arithmetic oracle/glass_cpu.py emulates for the
+ * fp16-storage parity tests.                                                                                         */
+int glass_conv2d_nhwc_h16(const glass_conv_desc* d, const void* x, const float* w, const float* bias, const void* residual,
+                          void* y, int flags, glass_stream_t stream);
+
 /* Winograd F(2x2,3x3) form of the same operator for the 3x3 / stride 1 / pad 1 layers (FPN output convs,
  * RPN head conv, every 3x3 of the ResNet trunk and of the local extractor's BasicBlocks, fusion output
  * conv): 2.25x fewer fp32 MFMA multiplies, results equal to glass_conv2d_nhwc to fp32 rounding
@@ -114,6 +124,9 @@ int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, cons
  * glass/modeling/fusion/local_feature_extraction.py:112,118,124). Padding acts as -inf. */
 int glass_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,
                          int ph, int pw, int Ho, int Wo, glass_stream_t stream);
+/* the same on fp16 tensors (fp16 storage mode): exact - the maximum of fp16 values is one of them */
+int glass_maxpool2d_nhwc_h16(const void* x, void* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,
+                             int ph, int pw, int Ho, int Wo, glass_stream_t stream);
 
 /* ------------------------------------------------------------------ image preprocess
  * (x - mean) / std per channel, CHW float [3,H,W] -> NHWC4 slot `n` of a zero-padded
@@ -145,6 +158,10 @@ typedef struct glass_roialign_desc {
 
 int glass_roi_align_rotated(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R, float* out,
                             glass_stream_t stream);
+/* the same with fp16 pyramid levels (d->feat[] point to IEEE fp16 NHWC tensors, d->ld[] in elements): taps are widened to
+ * fp32, interpolation and output are fp32 as above */
+int glass_roi_align_rotated_h16(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R,
+                                float* out, glass_stream_t stream);
 
 /* ------------------------------------------------------------------ rotated-box proposals
  * RRPN proposal selection for a whole batch and all pyramid levels (d2 RRPN.predict_proposals +

@@ -497,3 +497,102 @@ def test_conv_input_larger_than_2gib_takes_the_64bit_loads():
     idx[:4] = torch.tensor([0, 1, H * W - 2, H * W - 1])
     ref = x.view(-1, Cin)[idx] @ w.view(Cout, Cin).t() + b
     np.testing.assert_allclose(y.view(-1, Cout)[idx.to(dev)].cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)
+
+
+# ------------------------------------------------------------------ fp16 STORAGE (BASELINE configs[4]; MODEL.CONV_PRECISION fp16s)
+H16_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, relu, res_mode, x half, y half, residual half
+    (2, 20, 24, 64, 256, (3, 3), (1, 1), (1, 1), 1, 1, True, True, True),
+    (1, 33, 17, 128, 128, (3, 3), (1, 1), (1, 1), 0, 0, True, True, False),
+    (2, 16, 16, 256, 512, (1, 1), (2, 2), (0, 0), 0, 0, True, False, False),      # fp16 in, fp32 out (an exit of the fp16 chain)
+    (1, 40, 36, 4, 64, (7, 7), (2, 2), (3, 3), 1, 0, False, True, False),         # stem: fp32 image in, fp16 out (an entry)
+    (2, 32, 32, 16, 32, (3, 3), (1, 1), (1, 1), 1, 0, True, True, False),
+    (1, 16, 24, 512, 256, (1, 1), (1, 1), (0, 0), 0, 2, True, True, True),        # FPN lateral: x2-upsampled fp16 residual
+    (3, 7, 9, 64, 40, (1, 1), (1, 1), (0, 0), 2, 0, True, True, False),           # ragged rows and channel block (vector epilogue off: Cout % 4 == 0 but 40)
+    (2, 8, 32, 256, 256, (2, 1), (2, 1), (0, 0), 1, 0, True, True, False),
+    (1, 12, 20, 96, 136, (1, 1), (1, 1), (0, 0), 1, 1, True, False, True),        # fp16 residual into an fp32 output
+]
+
+
+@pytest.mark.parametrize("case", H16_CASES)
+def test_conv_fp16_storage_matches_emulation(case):
+    """glass_conv2d_nhwc_h16: y = fp16?(act(conv(fp16(x), fp16(w)) + bias [+ residual])) with fp32 accumulation.  fp32 outputs
+    match the emulation to fp32 summation order; fp16 outputs equal the emulation's rounding except where the fp32 value
+    sits on a rounding boundary (<= 1 fp16 ulp, rare)."""
+    from glass_amd.ops import native as K
+    N, H, W, Cin, Cout, k, s, p, relu, res_mode, xh, yh, rh = case
+    dev = _dev()
+    x = _rand((N, Cin, H, W), 31)
+    w = _rand((Cout, Cin, k[0], k[1]), 32, (2.0 / (Cin * k[0] * k[1])) ** 0.5)
+    b = _rand((Cout,), 33, 0.1)
+    if Cin == 4:
+        x[:, 3] = 0
+    xq = x.half().float() if True else x                      # the kernel rounds fp32 inputs to fp16 as well (operand rounding)
+    ref = F.conv2d(xq.double(), w.half().double(), b.double(), stride=s, padding=p)
+    res = None
+    if res_mode == 1:
+        res = _rand(tuple(ref.shape), 34)
+    elif res_mode == 2:
+        res = _rand((N, Cout, ref.shape[2] // 2, ref.shape[3] // 2), 34)
+    if res is not None and rh:
+        res = res.half().float()
+    if relu == 2:
+        ref = F.relu(ref)
+    if res_mode == 1:
+        ref = ref + res.double()
+    elif res_mode == 2:
+        ref = ref + F.interpolate(res.double(), scale_factor=2.0, mode="nearest")
+    if relu == 1:
+        ref = F.relu(ref)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    xd = nhwc(x).to(dev)
+    xd = xd.half() if xh else xd
+    rd = None
+    if res is not None:
+        rd = nhwc(res).to(dev)
+        rd = rd.half() if rh else rd
+    prev = K.set_conv_precision("fp16s")
+    try:
+        y = K.conv2d_nhwc(xd, nhwc(w).to(dev), b.to(dev), stride=s, padding=p, relu=relu, residual=rd, res_mode=res_mode,
+                          out_dtype=torch.float16 if yh else torch.float32)
+    finally:
+        K.set_conv_precision(prev)
+    torch.cuda.synchronize()
+    assert y.dtype == (torch.float16 if yh else torch.float32)
+    got = y.float().cpu().permute(0, 3, 1, 2).double()
+    scale = float(ref.abs().max())
+    if not yh:
+        err = float((got - ref).abs().max()) / scale
+        print(f"fp16-storage conv {case[:5]} fp32 out: max err / range {err:.2e}")
+        assert err <= 2e-6
+    else:
+        want = ref.float().half().double()                    # the emulation's own rounding of the exact result
+        big = torch.maximum(torch.maximum(got.abs(), want.abs()), torch.tensor(6.2e-5, dtype=torch.float64))
+        ulp = torch.ldexp(torch.ones_like(big), torch.frexp(big)[1] - 11)      # fp16 spacing at the larger of the two values
+        d = (got - want).abs()
+        frac_off = float((d > 0).double().mean())
+        print(f"fp16-storage conv {case[:5]} fp16 out: {frac_off:.2e} of the outputs differ from the emulation's rounding "
+              f"(max {float((d / ulp).max()):.2f} ulp)")
+        # (near zero the fp32 summation-order noise, ~1e-7 of the range, spans several fp16 subnormal steps)
+        assert bool((d <= 1.001 * ulp + 2e-6 * scale).all()) and frac_off < 5e-3
+
+
+def test_maxpool_and_roi_align_on_fp16_tensors():
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import make_boxes
+    from oracle import d2ops
+    dev = _dev()
+    x = _rand((2, 64, 37, 41), 41).half()
+    for kk, ss, pp in ((3, 2, 1), (2, 2, 0), ((2, 1), (2, 1), 0)):
+        y = K.maxpool2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), kk, ss, pp)
+        ref = F.max_pool2d(x.float(), kk, ss, pp)
+        assert y.dtype == torch.float16 and torch.equal(y.float().cpu().permute(0, 3, 1, 2), ref)
+    feats = [_rand((2, 256, 64 >> i, 80 >> i), 50 + i).half() for i in range(5)]
+    scales = [1.0 / (4 << i) for i in range(5)]
+    boxes = [make_boxes(i, 9, 256, 320) for i in range(2)]
+    ref = d2ops.roi_pooler([f.float() for f in feats], scales, boxes, (7, 7), 2)
+    bcat = torch.cat(boxes).contiguous()
+    bidx = torch.cat([torch.full((len(b),), i, dtype=torch.int32) for i, b in enumerate(boxes)])
+    y = K.roi_align_rotated([f.permute(0, 2, 3, 1).contiguous().to(dev) for f in feats], scales, bcat.to(dev), bidx.to(dev), (7, 7), 2)
+    assert y.dtype == torch.float32
+    np.testing.assert_allclose(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
