@@ -52,10 +52,11 @@ def parse():
     ap.add_argument("--side", type=int, default=SIDE)
     ap.add_argument("--rois", type=int, default=ROIS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "fp16s"],
                     help="fp32 (default: the reference's arithmetic, what the metric is quoted on) or fp16 = BASELINE configs[4]'s "
                          "precision: conv / linear operands rounded to fp16 on the fp16 matrix cores, fp32 accumulate and "
-                         "storage.  An fp16 run is a separate, reduced-precision measurement, never the headline value.")
+                         "storage; fp16s = the same arithmetic with the conv-path activations STORED as fp16 in HBM (fp16 storage).  "
+                         "An fp16 / fp16s run is a separate, reduced-precision measurement, never the headline value.")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="steps in flight (host-side software pipelining over HIP streams, glass_amd/utils/pipeline.py): "
                          "while the host waits for one step's count read-back the other step's kernels keep the GPU busy "
@@ -417,7 +418,9 @@ def main():
             "metric": "images/sec/GPU end-to-end spotting, 1000x1000, ~32 RoIs; 1/2/4/8 GPU scaling",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f16 operands, f32 accumulate/storage (reduced precision: not the headline)",
+            "dtype": "f32" if args.precision == "fp32" else
+                     ("f16 operands, f32 accumulate/storage (reduced precision: not the headline)" if args.precision == "fp16" else
+                      "f16 operands AND f16 activation storage on the conv path, f32 accumulate (reduced precision: not the headline)"),
             "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: backbone + RotatedROIAlign + recognition head, "
                                     f"{args.rois} RoIs/img, bs={B}/GPU, {args.side}x{args.side} (padded to /32), fp32")

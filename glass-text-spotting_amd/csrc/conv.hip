@@ -507,6 +507,8 @@ static int launch_conv_cfg(ConvParams& p, hipStream_t stream) {
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK>
 static int launch_conv_impl(ConvParams& p, hipStream_t stream) {
+  // (64-wide k-tiles for the fp16 kernels - 4 instead of 2 MFMAs per accumulator block and barrier pair - were measured
+  //  2.6x SLOWER: 148 vs 388 images/s in fp16 mode; the 144-byte LDS rows they need are not conflict-free)
   return p.half_mode ? launch_conv_cfg<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, true>(p, stream)
                      : launch_conv_cfg<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, false>(p, stream);
 }

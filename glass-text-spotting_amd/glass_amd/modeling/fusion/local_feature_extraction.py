@@ -60,7 +60,7 @@ class ResNetFeatureExtractor(InferenceModule):
                      out_cstride: int = 1) -> torch.Tensor:
         """x: [R,128,128,4] (NHWC4 crops) -> [R,8,32,256] (or into `out`)."""
         w = self.w
-        x = K.conv2d_nhwc(x, *w["conv0_1"], padding=1, relu=1)
+        x = K.conv2d_nhwc(x, *w["conv0_1"], padding=1, relu=1, out_dtype=K.act_dtype())      # entry of the fp16-storage chain
         x = K.conv2d_nhwc(x, *w["conv0_2"], padding=1, relu=1)
         pools = {1: ((2, 2), (2, 2), (0, 0)), 2: ((2, 2), (2, 2), (0, 0)), 3: ((2, 2), (2, 1), (0, 1))}
         for li, nblk in _LAYERS:
@@ -73,7 +73,9 @@ class ResNetFeatureExtractor(InferenceModule):
                 x = K.conv2d_nhwc(o, *w[key + "conv2"], padding=1, relu=1, residual=res, res_mode=1)
             if li < 4:
                 x = K.conv2d_nhwc(x, *w[f"conv{li}"], padding=1, relu=1)
-        return K.conv2d_nhwc(x, *w["conv4_1"], stride=(2, 1), relu=1, out=out, out_coff=out_coff, out_cstride=out_cstride)
+        # exit: fp32 (the fusion attention and everything after it read fp32)
+        return K.conv2d_nhwc(x, *w["conv4_1"], stride=(2, 1), relu=1, out=out, out_coff=out_coff, out_cstride=out_cstride,
+                             out_dtype=torch.float32)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         """reference call convention: logical NCHW [R,3,128,128] in, logical NCHW out."""

@@ -88,7 +88,7 @@ class RotatedRPN(InferenceModule):
         levels, keep_alive = [], []
         for lvl, f in enumerate(feats_nhwc):
             t = K.conv2d_nhwc(f, *self.w["conv"], padding=1, relu=1)
-            head = K.conv2d_nhwc(t, *self.w["heads"])            # [N,H,W,6A]: logits | deltas
+            head = K.conv2d_nhwc(t, *self.w["heads"], out_dtype=torch.float32)   # [N,H,W,6A]: logits | deltas (fp32: top-k input)
             keep_alive.append(head)
             ld = head.shape[-1]
             levels.append({"logits": head, "deltas": head.view(-1)[A:], "ldl": ld, "ldd": ld, "H": f.shape[1],
