@@ -19,7 +19,7 @@ INCLUDE = os.path.join(os.path.dirname(_ROOT), "include")
 SO_PATH = os.environ.get("GLASS_HIP_LIB") or os.path.join(_ROOT, "libglass_hip.so")   # override: kernel experiments
 
 EXPORTS = [
-    "glass_last_error", "glass_abi_version", "glass_device_count", "glass_conv2d_nhwc", "glass_conv2d_nhwc_f16", "glass_conv2d_nhwc_h16",
+    "glass_last_error", "glass_abi_version", "glass_device_count", "glass_conv2d_nhwc", "glass_conv2d_nhwc_f16", "glass_conv2d_nhwc_h16", "glass_local_stem_supported", "glass_local_stem_fused",
     "glass_winograd_supported", "glass_winograd_block_channels", "glass_winograd_weight_floats", "glass_winograd_pack_weights", "glass_conv3x3_winograd_nhwc",
     "glass_winograd43_supported", "glass_winograd43_weight_floats", "glass_winograd43_pack_weights", "glass_conv3x3_winograd43_nhwc",
     "glass_maxpool2d_nhwc", "glass_maxpool2d_nhwc_h16", "glass_roi_align_rotated_h16", "glass_pixel_shuffle2x_nhwc", "glass_sigmoid_inplace", "glass_paste_rotated_masks", "glass_mul_inplace",

@@ -60,11 +60,17 @@ class ResNetFeatureExtractor(InferenceModule):
                      out_cstride: int = 1) -> torch.Tensor:
         """x: [R,128,128,4] (NHWC4 crops) -> [R,8,32,256] (or into `out`)."""
         w = self.w
-        x = K.conv2d_nhwc(x, *w["conv0_1"], padding=1, relu=1, out_dtype=K.act_dtype())      # entry of the fp16-storage chain
-        x = K.conv2d_nhwc(x, *w["conv0_2"], padding=1, relu=1)
         pools = {1: ((2, 2), (2, 2), (0, 0)), 2: ((2, 2), (2, 2), (0, 0)), 3: ((2, 2), (2, 1), (0, 1))}
+        fused_stem = x.shape[0] > 0 and w["conv0_1"][1] is not None and w["conv0_2"][1] is not None and \
+            K.local_stem_supported(x, w["conv0_1"][0], w["conv0_2"][0])
+        if fused_stem:
+            # conv0_1 + conv0_2 + maxpool1 in one kernel (csrc/local_stem.hip): the 16- and 32-channel maps stay on the CU
+            x = K.local_stem_fused(x, *w["conv0_1"], *w["conv0_2"])
+        else:
+            x = K.conv2d_nhwc(x, *w["conv0_1"], padding=1, relu=1, out_dtype=K.act_dtype())      # entry of the fp16-storage chain
+            x = K.conv2d_nhwc(x, *w["conv0_2"], padding=1, relu=1)
         for li, nblk in _LAYERS:
-            if li in pools and x.shape[0] > 0:
+            if li in pools and x.shape[0] > 0 and not (fused_stem and li == 1):
                 x = K.maxpool2d_nhwc(x, *pools[li])
             for b in range(nblk):
                 key = f"l{li}.{b}."

@@ -120,6 +120,16 @@ int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, float* u_pa
 int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                   const float* residual, float* y, glass_stream_t stream);
 
+/* Fused head of the local-crop feature extractor (reference glass/modeling/fusion/local_feature_extraction.py:103-112):
+ * conv0_1 (3x3, 3->16) + BN + ReLU, conv0_2 (3x3, 16->32) + BN + ReLU, maxpool1 2x2 in ONE kernel - the two intermediate
+ * maps stay in LDS.  x [R,H,W,4] NHWC4 crops, w1 [16][3][3][4] / b1 [16], w2 [32][3][3][16] / b2 [32] (BatchNorm folded),
+ * y [R,H/2,W/2,32]; fp32.  Same results as the three separate entries up to fp32 summation order
+ * (tests/test_gpu_ops.py).  glass_local_stem_supported: H and W positive multiples of 32 (128 x 128 crops in every
+ * reference config) - otherwise callers use the separate entries.                                                   */
+int glass_local_stem_supported(int H, int W);
+int glass_local_stem_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
+                           int R, int H, int W, glass_stream_t stream);
+
 /* max pooling NHWC (d2 stem max_pool2d k3 s2 p1; local extractor maxpool1..3,
  * glass/modeling/fusion/local_feature_extraction.py:112,118,124). Padding acts as -inf. */
 int glass_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int KH, int KW, int sh, int sw,

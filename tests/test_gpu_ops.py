@@ -596,3 +596,32 @@ def test_maxpool_and_roi_align_on_fp16_tensors():
     y = K.roi_align_rotated([f.permute(0, 2, 3, 1).contiguous().to(dev) for f in feats], scales, bcat.to(dev), bidx.to(dev), (7, 7), 2)
     assert y.dtype == torch.float32
     np.testing.assert_allclose(y.cpu().permute(0, 3, 1, 2).numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("R,H,W", [(3, 128, 128), (2, 32, 64), (1, 96, 32)])
+def test_fused_local_stem_equals_the_three_separate_kernels(R, H, W):
+    """glass_local_stem_fused (conv0_1 + ReLU + conv0_2 + ReLU + maxpool 2x2 in one kernel) vs the separate entries and vs
+    torch fp64; borders of the image and of the 32 x 32 tiles included (conv0_2 pads its INPUT with zeros)."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    x = _rand((R, 3, H, W), 61) * 50.0
+    w1 = _rand((16, 3, 3, 3), 62, (2.0 / 27) ** 0.5)
+    b1 = _rand((16,), 63, 0.5)
+    w2 = _rand((32, 16, 3, 3), 64, (2.0 / 144) ** 0.5)
+    b2 = _rand((32,), 65, 0.5)
+    ref = F.max_pool2d(F.relu(F.conv2d(F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1)), w2.double(), b2.double(),
+                                       padding=1)), 2)
+    xd = F.pad(x.permute(0, 2, 3, 1), (0, 1)).contiguous().to(dev)
+    w1d = F.pad(w1.permute(0, 2, 3, 1), (0, 1)).contiguous().to(dev)
+    w2d = w2.permute(0, 2, 3, 1).contiguous().to(dev)
+    assert K.local_stem_supported(xd, w1d, w2d)
+    y = K.local_stem_fused(xd, w1d, b1.to(dev), w2d, b2.to(dev))
+    t = K.conv2d_nhwc(xd, w1d, b1.to(dev), padding=1, relu=1)
+    t = K.conv2d_nhwc(t, w2d, b2.to(dev), padding=1, relu=1)
+    y3 = K.maxpool2d_nhwc(t, 2, 2, 0)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    e_ref = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max()) / scale
+    e_sep = float((y - y3).abs().max()) / scale
+    print(f"fused local stem {R}x{H}x{W}: vs fp64 {e_ref:.2e}, vs separate kernels {e_sep:.2e} (of range)")
+    assert tuple(y.shape) == (R, H // 2, W // 2, 32) and e_ref < 2e-6 and e_sep < 2e-6
