@@ -15,7 +15,8 @@
 //     input channels.  Wave w owns the 32 output channels 32w..32w+31 for ALL 36 xi: 36 x 2 MFMA blocks of
 //     v_mfma_f32_16x16x4_f32 (rows = 16 channels, columns = the 16 tiles) = 288 accumulator registers.  Because a
 //     lane then holds all 36 xi of its (tile, 4-channel) outputs, the output transform At . A runs entirely in
-//     registers - no LDS exchange, no barrier in the epilogue - and ends in 32-byte-per-lane row stores.
+//     registers - no LDS exchange, no barrier in the epilogue - and ends in row stores (64 contiguous bytes per pixel and
+//     store instruction).
 //   * per k-tile: thread (tile, channel pair) fetches its raw 6x6 patch with 36 bounds-checked buffer_load_dwordx2
 //     (offset = row part + column part, an invalid part is 2^30 so that the sum is out of range: padding and ragged
 //     tiles are the hardware's zero fill; 12 offset registers instead of 36), applies Bt d B in place (12 six-point
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   };
 
   // ---- MFMA role: wave (wt, wc) owns tiles 16 wt + [0, 16) x channels n0 + 32 wc + [0, 32) for all 36 xi ----
-  // 16x16x4: A[i = lane&15][k = lane>>4] = weights (row i = 4 g' + e  <->  channel 32 wc + 8 g' + 4 cb + e),
+  // 16x16x4: A[i = lane&15][k = lane>>4] = weights (row i = 4 g' + e  <->  channel 32 wc + 16 cb + 4 g' + e),
   //          B[k = lane>>4][j = lane&15] = V (tile j);  C/D: lane holds rows 4 (lane>>4) + e, column lane&15.
   f32x4 acc[36][2];
 #pragma unroll
@@ -265,13 +266,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   }
 
   if constexpr (ABL == 4) stamp2 = __builtin_amdgcn_s_memtime();
-  // ---- epilogue: Y = At M A in registers; lane = (tile 16 wt + vj, channels n0 + 32 wc + 8 kg + 4 cb + e) ----
+  // ---- epilogue: Y = At M A in registers; lane = (tile 16 wt + vj, channels n0 + 32 wc + 16 cb + 4 kg + e) ----
   // 32-bit buffer addressing with split offsets (row part + column part; an invalid part = 2^30 makes the sum out of
   // range): a pixel that does not exist (ragged last tile block, H or W not a multiple of 4) loads zeros / drops the store.
   __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_mode == 1 ? p.res : p.y), 0,
                                                                  (int)(p.res_mode == 1 ? p.r_bytes : 0u), 0x00020000);
-  const int cbase = n0 + 32 * wc + 8 * kg;
+  const int cbase = n0 + 32 * wc + 4 * kg;      // + 16 cb: one store instruction covers 64 contiguous bytes per pixel
   const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
   unsigned yrow[4], ycol[4], rrow[4], rcol[4];
   {
@@ -305,14 +306,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          rres[cb][a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 16, 0));
+          rres[cb][a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 64, 0));
     }
   };
   load_res(ic<0>{});
   static_for<2>([&](auto cb_) {
     constexpr int cb = decltype(cb_)::value;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * cb);
+    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + cbase + 16 * cb);
     f32x4 out[16];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
         v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
         if (p.res_mode == 1) v = v + rres[cb][a * 4 + b];
         v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yrow[a] + ycol[b], cb * 16, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yrow[a] + ycol[b], cb * 64, 0);
       }
   });
   if constexpr (ABL == 4) {
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
 
 // U = G g G^t (6x6 per channel pair) in the fragment order the kernel streams:
 // [cout/(32 WC)][cin/KT][xi][wc][half][cb][lane][s]   with
-//   cout = 32 WC tn + 32 wc + 8 ((lane&15)>>2) + 4 cb + (lane&3),   cin = KT kt + 16 half + 4 (lane>>4) + s
+//   cout = 32 WC tn + 32 wc + 16 cb + 4 ((lane&15)>>2) + (lane&3),   cin = KT kt + 16 half + 4 (lane>>4) + s
 __global__ void wino43_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int WC, int KT) {
   const long total = 36L * Cout * Cin;
   const int nk = Cin / KT, halves = KT / 16;
@@ -370,7 +371,7 @@ __global__ void wino43_pack_weights_kernel(const float* __restrict__ w, float* _
     const int xi = (int)(r % 36); r /= 36;
     const int kt = (int)(r % nk);
     const int tn = (int)(r / nk);
-    const int co = tn * 32 * WC + 32 * wave + 8 * ((lane & 15) >> 2) + 4 * cb + (lane & 3);
+    const int co = tn * 32 * WC + 32 * wave + 16 * cb + 4 * ((lane & 15) >> 2) + (lane & 3);
     const int ci = kt * KT + 16 * half + 4 * (lane >> 4) + s;
     const int i = xi / 6, j = xi % 6;
     double acc = 0.0;

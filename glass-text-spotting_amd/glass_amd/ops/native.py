@@ -85,7 +85,7 @@ def conv_out_size(H, W, KH, KW, stride, padding):
 # 3x3/stride-1 layer runs.  Keyed by the weight's storage address; the entry pins the weight tensor so the
 # address cannot be recycled, and is re-packed if the tensor was modified in place (_version).
 _WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": collections.OrderedDict(), "max": 512,
-         "f43": os.environ.get("GLASS_WINOGRAD43", "1") != "0",
+         "f43": os.environ.get("GLASS_WINOGRAD43", "1") != "0", "pw": {"0": False, "all": "all"}.get(os.environ.get("GLASS_POINTWISE", "1"), True),
          "precision": os.environ.get("GLASS_CONV_PRECISION", "fp32")}
 
 
@@ -112,7 +112,7 @@ def act_dtype() -> torch.dtype:
 
 
 def last_conv_path() -> str:
-    """'winograd43' (conv3x3_wino43_f32), 'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct' or 'direct_fp16': which kernel
+    """'pointwise' (conv1x1_pw_f32), 'winograd43' (conv3x3_wino43_f32), 'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct' or 'direct_fp16': which kernel
     the most recent conv2d_nhwc call launched (bench/profiling aid)."""
     return _WINO.get("last_path", "direct")
 
@@ -133,17 +133,29 @@ def set_winograd43(enabled: bool) -> bool:
     return prev
 
 
-def winograd_pack(w: torch.Tensor, f43: bool = False) -> torch.Tensor:
-    """w [Cout,3,3,Cin] -> packed U for glass_conv3x3_winograd_nhwc (16*Cout*Cin floats) or, with f43, for
-    glass_conv3x3_winograd43_nhwc (36*Cout*Cin floats)."""
+def set_pointwise(enabled: bool) -> bool:
+    """Let eligible 1x1 convolutions (Cin % 32 == 0, Cout % 128 == 0) take the weight-streaming GEMM kernel (default on;
+    GLASS_POINTWISE=0: the implicit-GEMM kernel everywhere).  Returns the previous setting."""
+    prev = _WINO["pw"]
+    _WINO["pw"] = enabled if enabled == "all" else bool(enabled)      # "all": every supported layer (tests, micro-benchmarks)
+    return prev
+
+
+def winograd_pack(w: torch.Tensor, f43=False) -> torch.Tensor:
+    """w [Cout,3,3,Cin] -> packed U for glass_conv3x3_winograd_nhwc (16*Cout*Cin floats) or, with f43 True, for
+    glass_conv3x3_winograd43_nhwc (36*Cout*Cin floats); f43 == "pw": w [Cout,1,1,Cin] -> the fragment-ordered weights of
+    glass_conv1x1_pointwise_nhwc."""
     _f32c(w, "w")
     Cout, KH, KW, Cin = w.shape
     L = lib()
-    n = int((L.glass_winograd43_weight_floats if f43 else L.glass_winograd_weight_floats)(Cout, Cin))
-    u = torch.empty((n,), dtype=torch.float32, device=w.device)
-    fn = L.glass_winograd43_pack_weights if f43 else L.glass_winograd_pack_weights
-    check(fn(c_void_p(_dev(w, "w")), Cout, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())),
-          "glass_winograd43_pack_weights" if f43 else "glass_winograd_pack_weights")
+    if f43 == "pw":
+        nf, fn, what = L.glass_pointwise_weight_floats, L.glass_pointwise_pack_weights, "glass_pointwise_pack_weights"
+    elif f43:
+        nf, fn, what = L.glass_winograd43_weight_floats, L.glass_winograd43_pack_weights, "glass_winograd43_pack_weights"
+    else:
+        nf, fn, what = L.glass_winograd_weight_floats, L.glass_winograd_pack_weights, "glass_winograd_pack_weights"
+    u = torch.empty((int(nf(Cout, Cin)),), dtype=torch.float32, device=w.device)
+    check(fn(c_void_p(_dev(w, "w")), Cout, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())), what)
     return u
 
 
@@ -157,7 +169,7 @@ def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int) -> bool:
     return waste <= 1.25 and blocks >= 192
 
 
-def _winograd_weights(w: torch.Tensor, f43: bool = False) -> torch.Tensor:
+def _winograd_weights(w: torch.Tensor, f43=False) -> torch.Tensor:
     cache = _WINO["cache"]
     key = (w.data_ptr(), tuple(w.shape), f43)
     ent = cache.get(key)
@@ -224,6 +236,19 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                                           c_void_p(_dev(bias, "bias") if bias is not None else None),
                                           c_void_p(_dev(residual, "residual") if residual is not None else None),
                                           c_void_p(_dev(out, "out")), c_void_p(stream_handle())), "glass_conv2d_nhwc_f16")
+        return out
+    # the weight-streaming 1x1 kernel wins where the k-loop is long enough and the grid fills the chip (measured,
+    # scripts/bench_conv.py: 256->1024 and 256->256 x1.11, 1024->256 x1.05; 64->256 x0.90, 512->2048 @32x32 x0.91,
+    # 512->128 x0.96)
+    if (winograd is None and _WINO["pw"] and KH == 1 and KW == 1 and (_WINO["pw"] == "all" or (Cin >= 256 and Cout >= 256 and N * Ho * Wo >= 16384))
+            and lib().glass_pointwise_supported(ctypes.byref(d))):
+        u = _winograd_weights(w, "pw")
+        _WINO["last_path"] = "pointwise"
+        check(lib().glass_conv1x1_pointwise_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
+                                                 c_void_p(_dev(bias, "bias") if bias is not None else None),
+                                                 c_void_p(_dev(residual, "residual") if residual is not None else None),
+                                                 c_void_p(_dev(out, "out")), c_void_p(stream_handle())),
+              "glass_conv1x1_pointwise_nhwc")
         return out
     use_wino = _WINO["enabled"] if winograd is None else winograd
     if winograd is None and use_wino and KH == 3:

@@ -120,6 +120,18 @@ int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, float* u_pa
 int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                   const float* residual, float* y, glass_stream_t stream);
 
+/* 1x1 convolution as a weight-streaming GEMM (csrc/pointwise.hip): the bottleneck / lateral / shortcut 1x1 layers with
+ * Cin % 32 == 0 and Cout % 128 == 0, any square stride, pad 0.  Same descriptor, epilogue semantics (bias, ReLU before /
+ * after the residual, same-size or x2-upsampled residual, channel-offset output) and fp32 arithmetic as
+ * glass_conv2d_nhwc - an exact-fp32 fma chain, results equal to it up to summation order; `u_packed` replaces `w`:
+ * glass_pointwise_pack_weights lays W [Cout][Cin] out in MFMA fragment order (Cout * Cin floats) once per layer.
+ * glass_pointwise_supported(d) == 0 -> callers use glass_conv2d_nhwc.                                               */
+int glass_pointwise_supported(const glass_conv_desc* d);
+size_t glass_pointwise_weight_floats(int Cout, int Cin);
+int glass_pointwise_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream);
+int glass_conv1x1_pointwise_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
+                                 const float* residual, float* y, glass_stream_t stream);
+
 /* Fused head of the local-crop feature extractor (reference glass/modeling/fusion/local_feature_extraction.py:103-112):
  * conv0_1 (3x3, 3->16) + BN + ReLU, conv0_2 (3x3, 16->32) + BN + ReLU, maxpool1 2x2 in ONE kernel - the two intermediate
  * maps stay in LDS.  x [R,H,W,4] NHWC4 crops, w1 [16][3][3][4] / b1 [16], w2 [32][3][3][16] / b2 [32] (BatchNorm folded),

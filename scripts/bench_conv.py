@@ -55,11 +55,18 @@ for name, N, H, W, Cin, Cout, k, s, p in LAYERS:
     x = torch.randn((N, H, W, Cin), device=dev)
     w = torch.randn((Cout, k, k, Cin), device=dev) * 0.05
     b = torch.randn((Cout,), device=dev)
+    K.set_pointwise(False)
     y = K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, winograd=False)
     ms = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y, winograd=False))
+    K.set_pointwise("all")
     flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * Cin * k * k
     line = f"{name:36s} direct {ms:8.3f} ms {flops / ms / 1e9:7.1f} TFLOP/s"
     d = K.ConvDesc(N, H, W, Cin, Cout, k, k, s, s, p, p, y.shape[1], y.shape[2], Cin, Cout, 0, 1, 1, 0, 0)
+    if k == 1 and K.lib().glass_pointwise_supported(K.ctypes.byref(d)):
+        yp = torch.empty_like(y)
+        msp = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=yp))
+        err = float((yp - y).abs().max() / y.abs().max())
+        line += f" | pointwise {msp:8.3f} ms {flops / msp / 1e9:7.1f} TFLOP/s  x{ms / msp:.2f}  rel.err {err:.1e}"
     if k == 3 and K.lib().glass_winograd_supported(K.ctypes.byref(d)):
         y2 = torch.empty_like(y)
         msw = timed(lambda: K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y2, winograd=True))

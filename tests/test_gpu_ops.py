@@ -625,3 +625,75 @@ def test_fused_local_stem_equals_the_three_separate_kernels(R, H, W):
     e_sep = float((y - y3).abs().max()) / scale
     print(f"fused local stem {R}x{H}x{W}: vs fp64 {e_ref:.2e}, vs separate kernels {e_sep:.2e} (of range)")
     assert tuple(y.shape) == (R, H // 2, W // 2, 32) and e_ref < 2e-6 and e_sep < 2e-6
+
+
+PW_CASES = [
+    # N, H, W, Cin, Cout, stride, relu, res_mode, (ld_out, coff)
+    (2, 20, 24, 64, 256, 1, 1, 1, None),          # res2 conv3 + residual
+    (1, 33, 17, 128, 128, 1, 0, 0, None),         # ragged pixel count
+    (2, 16, 16, 256, 512, 2, 0, 0, None),         # stride-2 shortcut
+    (1, 16, 24, 512, 256, 1, 0, 2, None),         # FPN lateral with the x2-upsampled residual
+    (3, 7, 9, 96, 128, 1, 2, 1, None),            # 3 k-tiles (odd), ReLU before the residual add
+    (1, 12, 20, 32, 384, 1, 1, 0, (512, 128)),    # a single k-tile, three channel blocks into a wider buffer at an offset
+    (8, 64, 64, 256, 256, 1, 1, 0, None),         # enough pixels for the 256-pixel blocks
+    (2, 15, 15, 2048, 512, 2, 1, 0, None),        # 64 k-tiles, odd map with stride 2
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_pointwise_matches_direct_and_torch(case):
+    """glass_conv1x1_pointwise_nhwc (weight-streaming 1x1 GEMM) vs torch fp64 and vs glass_conv2d_nhwc: same exact-fp32
+    arithmetic, different summation order -> 5e-6 of the output range (K up to 2048 terms)."""
+    from glass_amd.ops import native as K
+    N, H, W, Cin, Cout, stride, relu, res_mode, strided = case
+    dev = _dev()
+    K.set_pointwise("all")
+    x = _rand((N, Cin, H, W), 71)
+    w = _rand((Cout, Cin, 1, 1), 72, (2.0 / Cin) ** 0.5)
+    b = _rand((Cout,), 73, 0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride)
+    res = None
+    if res_mode == 1:
+        res = _rand(tuple(ref.shape), 74)
+    elif res_mode == 2:
+        res = _rand((N, Cout, ref.shape[2] // 2, ref.shape[3] // 2), 74)
+    if relu == 2:
+        ref = F.relu(ref)
+    if res_mode == 1:
+        ref = ref + res.double()
+    elif res_mode == 2:
+        ref = ref + F.interpolate(res.double(), scale_factor=2.0, mode="nearest")
+    if relu == 1:
+        ref = F.relu(ref)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    xd, wd = nhwc(x).to(dev), nhwc(w).to(dev)
+    rd = None if res is None else nhwc(res).to(dev)
+    kw = dict(stride=stride, relu=relu, residual=rd, res_mode=res_mode)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    if strided is None:
+        y = K.conv2d_nhwc(xd, wd, b.to(dev), **kw)
+        assert K.last_conv_path() == "pointwise"
+        K.set_pointwise(False)
+        yd = K.conv2d_nhwc(xd, wd, b.to(dev), **kw)
+        K.set_pointwise(True)
+        assert K.last_conv_path() == "direct"
+    else:
+        ld, coff = strided
+        buf = torch.full((N, Ho, Wo, ld), 7.0, device=dev)
+        bufd = torch.full((N, Ho, Wo, ld), 7.0, device=dev)
+        K.conv2d_nhwc(xd, wd, b.to(dev), out=buf, out_coff=coff, **kw)
+        assert K.last_conv_path() == "pointwise"
+        K.set_pointwise(False)
+        K.conv2d_nhwc(xd, wd, b.to(dev), out=bufd, out_coff=coff, **kw)
+        K.set_pointwise(True)
+        torch.cuda.synchronize()
+        assert float((buf[..., :coff] - 7.0).abs().max()) == 0.0
+        assert coff + Cout == ld or float((buf[..., coff + Cout:] - 7.0).abs().max()) == 0.0
+        y, yd = buf[..., coff:coff + Cout], bufd[..., coff:coff + Cout]
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    e = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max()) / scale
+    ed = float((y - yd).abs().max()) / scale
+    print(f"pointwise {case[:6]}: vs fp64 {e:.2e}, vs implicit-GEMM kernel {ed:.2e} (of range)")
+    K.set_pointwise(True)
+    assert e <= 5e-6 and ed <= 5e-6
