@@ -135,7 +135,7 @@ class ConvMeter:
 
     def summary(self):
         out = {k: {"launches": 0, "ms": 0.0, "algo_flops": 0.0, "exec_flops": 0.0}
-               for k in ("winograd43", "winograd128", "winograd", "pointwise", "direct", "direct_fp16")}
+               for k in ("winograd43", "winograd128", "winograd", "pointwise", "direct", "direct_fp16", "packed_fp16")}
         for p, _xs, _ws, _st, _res, algo, ex, ms in self._launches():
             f = out[p]
             f["launches"] += 1
@@ -379,9 +379,10 @@ def main():
                  "winograd": "conv3x3_wino_f32 (Winograd F(2x2,3x3), fp32 MFMA, 64 tiles x 64 channels per workgroup)",
                  "pointwise": "conv1x1_pw_f32 (fp32 MFMA 16x16x4 weight-streaming 1x1 GEMM)",
                  "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
-                 "direct_fp16": "conv_igemm_f32<..., HALF> (fp16 MFMA implicit-GEMM conv/linear, fp32 accumulate)"}
+                 "direct_fp16": "conv_igemm_f32<..., HALF> (fp16 MFMA implicit-GEMM conv/linear, fp32 accumulate)",
+                 "packed_fp16": "conv_h16_kernel (fp16 MFMA 16x16x32 weight-streaming implicit-GEMM conv on fp16 tensors, fp32 accumulate)"}
         PKEY = {"winograd43": "conv3x3_wino43_f32", "winograd128": "conv3x3_wino128_f32", "winograd": "conv3x3_wino_f32", "pointwise": "conv1x1_pw_f32", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
-                "direct_fp16": "conv_igemm_f16"}
+                "direct_fp16": "conv_igemm_f16", "packed_fp16": "conv_h16_kernel"}
         PEAK = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else FP16_MFMA_PEAK_TFLOPS
         dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time
         # PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate

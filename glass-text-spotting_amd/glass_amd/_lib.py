@@ -21,6 +21,7 @@ SO_PATH = os.environ.get("GLASS_HIP_LIB") or os.path.join(_ROOT, "libglass_hip.s
 EXPORTS = [
     "glass_last_error", "glass_abi_version", "glass_device_count", "glass_conv2d_nhwc", "glass_conv2d_nhwc_f16", "glass_conv2d_nhwc_h16", "glass_local_stem_supported", "glass_local_stem_fused",
     "glass_pointwise_supported", "glass_pointwise_weight_floats", "glass_pointwise_pack_weights", "glass_conv1x1_pointwise_nhwc",
+    "glass_conv_h16_supported", "glass_conv_h16_weight_halves", "glass_conv_h16_pack_weights", "glass_conv2d_nhwc_h16_packed",
     "glass_winograd_supported", "glass_winograd_block_channels", "glass_winograd_weight_floats", "glass_winograd_pack_weights", "glass_conv3x3_winograd_nhwc",
     "glass_winograd43_supported", "glass_winograd43_weight_floats", "glass_winograd43_pack_weights", "glass_conv3x3_winograd43_nhwc",
     "glass_maxpool2d_nhwc", "glass_maxpool2d_nhwc_h16", "glass_roi_align_rotated_h16", "glass_pixel_shuffle2x_nhwc", "glass_sigmoid_inplace", "glass_paste_rotated_masks", "glass_mul_inplace",
@@ -100,6 +101,7 @@ def lib() -> ctypes.CDLL:
         L.glass_winograd_weight_floats.restype = ctypes.c_size_t
         L.glass_winograd43_weight_floats.restype = ctypes.c_size_t
         L.glass_pointwise_weight_floats.restype = ctypes.c_size_t
+        L.glass_conv_h16_weight_halves.restype = ctypes.c_size_t
         L.glass_bilstm_workspace_bytes.restype = ctypes.c_int64
         L.glass_decode_workspace_bytes.restype = ctypes.c_int64
         _LIB = L

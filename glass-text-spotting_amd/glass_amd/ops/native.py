@@ -86,7 +86,7 @@ def conv_out_size(H, W, KH, KW, stride, padding):
 # address cannot be recycled, and is re-packed if the tensor was modified in place (_version).
 _WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": collections.OrderedDict(), "max": 512,
          "f43": os.environ.get("GLASS_WINOGRAD43", "1") != "0", "pw": {"0": False, "all": "all"}.get(os.environ.get("GLASS_POINTWISE", "1"), True),
-         "precision": os.environ.get("GLASS_CONV_PRECISION", "fp32")}
+         "precision": os.environ.get("GLASS_CONV_PRECISION", "fp32"), "h16": os.environ.get("GLASS_CONV_H16", "1") != "0"}
 
 
 def set_conv_precision(precision: str) -> str:
@@ -112,7 +112,7 @@ def act_dtype() -> torch.dtype:
 
 
 def last_conv_path() -> str:
-    """'pointwise' (conv1x1_pw_f32), 'winograd43' (conv3x3_wino43_f32), 'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct' or 'direct_fp16': which kernel
+    """'pointwise' (conv1x1_pw_f32), 'winograd43' (conv3x3_wino43_f32), 'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct', 'direct_fp16' (fp32 template, fp16 operands) or 'packed_fp16' (conv_h16_kernel): which kernel
     the most recent conv2d_nhwc call launched (bench/profiling aid)."""
     return _WINO.get("last_path", "direct")
 
@@ -133,6 +133,15 @@ def set_winograd43(enabled: bool) -> bool:
     return prev
 
 
+def set_conv_h16(enabled: bool) -> bool:
+    """Let fp16-input convolutions with Cin % 64 == 0 and Cout % 64 == 0 take the packed-weight fp16 kernel
+    (glass_conv2d_nhwc_h16_packed; default on, GLASS_CONV_H16=0: the fp32 template with fp16 operands everywhere).
+    Returns the previous setting."""
+    prev = _WINO["h16"]
+    _WINO["h16"] = bool(enabled)
+    return prev
+
+
 def set_pointwise(enabled: bool) -> bool:
     """Let eligible 1x1 convolutions (Cin % 32 == 0, Cout % 128 == 0) take the weight-streaming GEMM kernel (default on;
     GLASS_POINTWISE=0: the implicit-GEMM kernel everywhere).  Returns the previous setting."""
@@ -144,10 +153,16 @@ def set_pointwise(enabled: bool) -> bool:
 def winograd_pack(w: torch.Tensor, f43=False) -> torch.Tensor:
     """w [Cout,3,3,Cin] -> packed U for glass_conv3x3_winograd_nhwc (16*Cout*Cin floats) or, with f43 True, for
     glass_conv3x3_winograd43_nhwc (36*Cout*Cin floats); f43 == "pw": w [Cout,1,1,Cin] -> the fragment-ordered weights of
-    glass_conv1x1_pointwise_nhwc."""
+    glass_conv1x1_pointwise_nhwc; f43 == "h16": w [Cout,KH,KW,Cin] -> the fp16 fragment-ordered weights of
+    glass_conv2d_nhwc_h16_packed."""
     _f32c(w, "w")
     Cout, KH, KW, Cin = w.shape
     L = lib()
+    if f43 == "h16":
+        u = torch.empty((int(L.glass_conv_h16_weight_halves(Cout, KH, KW, Cin)),), dtype=torch.float16, device=w.device)
+        check(L.glass_conv_h16_pack_weights(c_void_p(_dev(w, "w")), Cout, KH, KW, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())),
+              "glass_conv_h16_pack_weights")
+        return u
     if f43 == "pw":
         nf, fn, what = L.glass_pointwise_weight_floats, L.glass_pointwise_pack_weights, "glass_pointwise_pack_weights"
     elif f43:
@@ -224,6 +239,18 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
             raise GlassLibraryError("float16 activation tensors need conv precision 'fp16s' (and no forced Winograd)")
         flags = (1 if x.dtype == torch.float16 else 0) | (2 if out.dtype == torch.float16 else 0) | \
                 (4 if residual is not None and residual.dtype == torch.float16 else 0)
+        # fp16 input, Cin / Cout multiples of 64: the kernel built for the fp16 matrix cores (csrc/conv_h16.hip, weights
+        # pre-rounded and packed once); everything else - fp32 entries, the 4/16/32-channel first layers, the narrow heads -
+        # stays on the fp32 template with fp16 operands
+        if _WINO["h16"] and lib().glass_conv_h16_supported(ctypes.byref(d), int(flags)):
+            u = _winograd_weights(w, "h16")
+            _WINO["last_path"] = "packed_fp16"
+            check(lib().glass_conv2d_nhwc_h16_packed(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
+                                                     c_void_p(_dev(bias, "bias") if bias is not None else None),
+                                                     c_void_p(_dev(residual, "residual") if residual is not None else None),
+                                                     c_void_p(_dev(out, "out")), int(flags), c_void_p(stream_handle())),
+                  "glass_conv2d_nhwc_h16_packed")
+            return out
         _WINO["last_path"] = "direct_fp16"
         check(lib().glass_conv2d_nhwc_h16(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
                                           c_void_p(_dev(bias, "bias") if bias is not None else None),

@@ -81,6 +81,21 @@ int glass_conv2d_nhwc_f16(const glass_conv_desc* d, const float* x, const float*
 int glass_conv2d_nhwc_h16(const glass_conv_desc* d, const void* x, const float* w, const float* bias, const void* residual,
                           void* y, int flags, glass_stream_t stream);
 
+/* The fp16-storage convolution built for the fp16 matrix cores (csrc/conv_h16.hip): same operator, descriptor, flags and
+ * arithmetic as glass_conv2d_nhwc_h16 - fp16?(act(conv(fp16(x), fp16(w)) + bias [+ residual])), fp32 accumulation on
+ * v_mfma_f32_16x16x32_f16 - for the layers whose INPUT is an fp16 tensor (flags bit 0 set) with Cin % 64 == 0 and
+ * Cout % 64 == 0: any kernel size up to 32 taps, any stride / zero padding, same-size or x2-upsampled residual,
+ * channel-offset output.  `u_packed` replaces `w`: glass_conv_h16_pack_weights rounds W [Cout][KH][KW][Cin] to fp16
+ * (round to nearest even - the rounding glass_conv2d_nhwc_h16 applies while staging) and lays it out in MFMA fragment
+ * order (Cout*KH*KW*Cin halves) once per layer.  Results equal glass_conv2d_nhwc_h16 up to fp32 summation order.
+ * glass_conv_h16_supported(d, flags) == 0 (fp32 input, other channel counts, rows not 16-byte aligned, operands
+ * >= 2 GiB) -> callers use glass_conv2d_nhwc_h16.                                                                  */
+int glass_conv_h16_supported(const glass_conv_desc* d, int flags);
+size_t glass_conv_h16_weight_halves(int Cout, int KH, int KW, int Cin);
+int glass_conv_h16_pack_weights(const float* w, int Cout, int KH, int KW, int Cin, void* u_packed, glass_stream_t stream);
+int glass_conv2d_nhwc_h16_packed(const glass_conv_desc* d, const void* x, const void* u_packed, const float* bias,
+                                 const void* residual, void* y, int flags, glass_stream_t stream);
+
 /* Winograd F(2x2,3x3) form of the same operator for the 3x3 / stride 1 / pad 1 layers (FPN output convs,
  * RPN head conv, every 3x3 of the ResNet trunk and of the local extractor's BasicBlocks, fusion output
  * conv): 2.25x fewer fp32 MFMA multiplies, results equal to glass_conv2d_nhwc to fp32 rounding

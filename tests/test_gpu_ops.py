@@ -511,16 +511,27 @@ H16_CASES = [
     (3, 7, 9, 64, 40, (1, 1), (1, 1), (0, 0), 2, 0, True, True, False),           # ragged rows and channel block (vector epilogue off: Cout % 4 == 0 but 40)
     (2, 8, 32, 256, 256, (2, 1), (2, 1), (0, 0), 1, 0, True, True, False),
     (1, 12, 20, 96, 136, (1, 1), (1, 1), (0, 0), 1, 1, True, False, True),        # fp16 residual into an fp32 output
+    # the four shapes of conv_h16_kernel: 256 x 128 / 128 x 128 / 256 x 64 / 128 x 64 pixel x channel blocks
+    (8, 64, 64, 64, 384, (3, 3), (1, 1), (1, 1), 1, 1, True, True, True),
+    (8, 64, 60, 128, 192, (3, 3), (1, 1), (1, 1), 2, 1, True, True, False),
+    (2, 13, 11, 192, 64, (3, 3), (2, 2), (1, 1), 1, 0, True, False, False),       # ragged last block, stride 2 with padding
+    (1, 9, 9, 64, 128, (5, 5), (1, 1), (2, 2), 0, 0, True, True, False),          # 25 taps, most of them padding at the rim
+    (4, 1, 1, 1024, 256, (1, 1), (1, 1), (0, 0), 1, 0, True, False, False),       # a linear layer: 4 pixels in a 128-pixel block
 ]
 
 
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("case", H16_CASES)
-def test_conv_fp16_storage_matches_emulation(case):
-    """glass_conv2d_nhwc_h16: y = fp16?(act(conv(fp16(x), fp16(w)) + bias [+ residual])) with fp32 accumulation.  fp32 outputs
-    match the emulation to fp32 summation order; fp16 outputs equal the emulation's rounding except where the fp32 value
-    sits on a rounding boundary (<= 1 fp16 ulp, rare)."""
+def test_conv_fp16_storage_matches_emulation(case, packed):
+    """glass_conv2d_nhwc_h16 / glass_conv2d_nhwc_h16_packed (the fp16-MFMA kernel of csrc/conv_h16.hip, taken when the input
+    is fp16 and Cin, Cout are multiples of 64): y = fp16?(act(conv(fp16(x), fp16(w)) + bias [+ residual])) with fp32
+    accumulation.  fp32 outputs match the emulation to fp32 summation order; fp16 outputs equal the emulation's rounding
+    except where the fp32 value sits on a rounding boundary (<= 1 fp16 ulp, rare)."""
     from glass_amd.ops import native as K
     N, H, W, Cin, Cout, k, s, p, relu, res_mode, xh, yh, rh = case
+    takes_packed = packed and xh and Cin % 64 == 0 and Cout % 64 == 0
+    if packed and not takes_packed:
+        pytest.skip("layer is outside the packed kernel's envelope (covered by packed=False)")
     dev = _dev()
     x = _rand((N, Cin, H, W), 31)
     w = _rand((Cout, Cin, k[0], k[1]), 32, (2.0 / (Cin * k[0] * k[1])) ** 0.5)
@@ -551,12 +562,14 @@ def test_conv_fp16_storage_matches_emulation(case):
     if res is not None:
         rd = nhwc(res).to(dev)
         rd = rd.half() if rh else rd
-    prev = K.set_conv_precision("fp16s")
+    prev, prev_h = K.set_conv_precision("fp16s"), K.set_conv_h16(packed)
     try:
         y = K.conv2d_nhwc(xd, nhwc(w).to(dev), b.to(dev), stride=s, padding=p, relu=relu, residual=rd, res_mode=res_mode,
                           out_dtype=torch.float16 if yh else torch.float32)
+        assert K.last_conv_path() == ("packed_fp16" if takes_packed else "direct_fp16")
     finally:
         K.set_conv_precision(prev)
+        K.set_conv_h16(prev_h)
     torch.cuda.synchronize()
     assert y.dtype == (torch.float16 if yh else torch.float32)
     got = y.float().cpu().permute(0, 3, 1, 2).double()
