@@ -323,21 +323,24 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 
 def local_stem_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
-    """the fused conv0_1 + conv0_2 + maxpool kernel takes fp32 NHWC4 crops with H, W multiples of 32 (fp32 precision)"""
-    return (_WINO["precision"] == "fp32" and os.environ.get("GLASS_LOCAL_STEM", "1") != "0" and x.dtype == torch.float32 and
+    """the fused conv0_1 + conv0_2 + maxpool kernel takes fp32 NHWC4 crops with H, W multiples of 32 (precision fp32, or
+    fp16s: the fp16-storage arithmetic, fp16 output)"""
+    return (_WINO["precision"] in ("fp32", "fp16s") and os.environ.get("GLASS_LOCAL_STEM", "1") != "0" and x.dtype == torch.float32 and
             x.dim() == 4 and x.shape[-1] == 4 and tuple(w1.shape) == (16, 3, 3, 4) and tuple(w2.shape) == (32, 3, 3, 16) and
             bool(lib().glass_local_stem_supported(int(x.shape[1]), int(x.shape[2]))))
 
 
 def local_stem_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
-    """x [R,H,W,4] -> maxpool2x2(relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2)) [R,H/2,W/2,32] in one kernel."""
+    """x [R,H,W,4] -> maxpool2x2(relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2)) [R,H/2,W/2,32] in one kernel; in 'fp16s'
+    mode with the fp16 roundings of the unfused fp16-storage chain and an fp16 output."""
     for t, n in ((x, "x"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
         _f32c(t, n)
     R, H, W, _ = x.shape
-    y = torch.empty((R, H // 2, W // 2, 32), dtype=torch.float32, device=x.device)
-    check(lib().glass_local_stem_fused(c_void_p(_dev(x)), c_void_p(_dev(w1)), c_void_p(_dev(b1)), c_void_p(_dev(w2)),
-                                       c_void_p(_dev(b2)), c_void_p(_dev(y)), R, H, W, c_void_p(stream_handle())),
-          "glass_local_stem_fused")
+    h16 = _WINO["precision"] == "fp16s"
+    y = torch.empty((R, H // 2, W // 2, 32), dtype=torch.float16 if h16 else torch.float32, device=x.device)
+    fn = lib().glass_local_stem_fused_h16 if h16 else lib().glass_local_stem_fused
+    check(fn(c_void_p(_dev(x)), c_void_p(_dev(w1)), c_void_p(_dev(b1)), c_void_p(_dev(w2)), c_void_p(_dev(b2)), c_void_p(_dev(y)),
+             R, H, W, c_void_p(stream_handle())), "glass_local_stem_fused")
     return y
 
 

@@ -156,6 +156,11 @@ int glass_conv1x1_pointwise_nhwc(const glass_conv_desc* d, const float* x, const
 int glass_local_stem_supported(int H, int W);
 int glass_local_stem_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
                            int R, int H, int W, glass_stream_t stream);
+/* fp16-storage form (conv precision "fp16s"): fp32 crops and weights in, operands rounded to fp16 (round to nearest even),
+ * fp32 accumulation, the conv0_1 map rounded to fp16 where the separate entries store it, y [R,H/2,W/2,32] written as
+ * fp16 - the results of glass_conv2d_nhwc_h16 x 2 + glass_maxpool2d_nhwc_h16 up to fp32 summation order.            */
+int glass_local_stem_fused_h16(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
+                               int R, int H, int W, glass_stream_t stream);
 
 /* max pooling NHWC (d2 stem max_pool2d k3 s2 p1; local extractor maxpool1..3,
  * glass/modeling/fusion/local_feature_extraction.py:112,118,124). Padding acts as -inf. */

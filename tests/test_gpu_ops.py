@@ -640,6 +640,48 @@ def test_fused_local_stem_equals_the_three_separate_kernels(R, H, W):
     assert tuple(y.shape) == (R, H // 2, W // 2, 32) and e_ref < 2e-6 and e_sep < 2e-6
 
 
+@pytest.mark.parametrize("R,H,W", [(3, 128, 128), (2, 32, 64)])
+def test_fused_local_stem_fp16_storage_equals_the_separate_fp16_kernels(R, H, W):
+    """glass_local_stem_fused_h16 ('fp16s' mode) vs glass_conv2d_nhwc_h16 x 2 + glass_maxpool2d_nhwc_h16: the same fp16
+    roundings (operands, the stored conv0_1 map, the output), so fp16 outputs agree except where an fp32 sum sits on a rounding
+    boundary (<= 1 fp16 ulp, rare) - and vs the fp64 emulation of that arithmetic."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    x = _rand((R, 3, H, W), 71) * 2.0
+    w1 = _rand((16, 3, 3, 3), 72, (2.0 / 27) ** 0.5)
+    b1 = _rand((16,), 73, 0.5)
+    w2 = _rand((32, 16, 3, 3), 74, (2.0 / 144) ** 0.5)
+    b2 = _rand((32,), 75, 0.5)
+    q = lambda t: t.half().double()
+    t1 = F.relu(F.conv2d(q(x), q(w1), b1.double(), padding=1)).float().half().double()
+    ref = F.max_pool2d(F.relu(F.conv2d(t1, q(w2), b2.double(), padding=1)), 2).float().half().double()
+    xd = F.pad(x.permute(0, 2, 3, 1), (0, 1)).contiguous().to(dev)
+    w1d = F.pad(w1.permute(0, 2, 3, 1), (0, 1)).contiguous().to(dev)
+    w2d = w2.permute(0, 2, 3, 1).contiguous().to(dev)
+    prev = K.set_conv_precision("fp16s")
+    try:
+        assert K.local_stem_supported(xd, w1d, w2d)
+        y = K.local_stem_fused(xd, w1d, b1.to(dev), w2d, b2.to(dev))
+        t = K.conv2d_nhwc(xd, w1d, b1.to(dev), padding=1, relu=1, out_dtype=torch.float16)
+        t = K.conv2d_nhwc(t, w2d, b2.to(dev), padding=1, relu=1)
+        y3 = K.maxpool2d_nhwc(t, 2, 2, 0)
+    finally:
+        K.set_conv_precision(prev)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.float16 and y3.dtype == torch.float16 and tuple(y.shape) == (R, H // 2, W // 2, 32)
+    got, sep = y.float().cpu().permute(0, 3, 1, 2).double(), y3.float().cpu().permute(0, 3, 1, 2).double()
+    scale = float(ref.abs().max())
+    for name, other in (("separate fp16 kernels", sep), ("fp64 emulation", ref)):
+        big = torch.maximum(torch.maximum(got.abs(), other.abs()), torch.tensor(6.2e-5, dtype=torch.float64))
+        ulp = torch.ldexp(torch.ones_like(big), torch.frexp(big)[1] - 11)
+        d = (got - other).abs()
+        frac = float((d > 0).double().mean())
+        print(f"fused fp16 local stem {R}x{H}x{W} vs {name}: {frac:.2e} of the outputs differ (max {float((d / ulp).max()):.2f} ulp)")
+        # a conv0_1 value on a rounding boundary moves by one fp16 ulp and shifts the conv0_2 sums that read it by ~1e-4 of
+        # the range: still at most one ulp of the (larger) output, on a few outputs
+        assert bool((d <= 1.001 * ulp + 1e-3 * scale).all()) and frac < 2e-2
+
+
 PW_CASES = [
     # N, H, W, Cin, Cout, stride, relu, res_mode, (ld_out, coff)
     (2, 20, 24, 64, 256, 1, 1, 1, None),          # res2 conv3 + residual
