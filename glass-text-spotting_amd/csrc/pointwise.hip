@@ -7,8 +7,9 @@
 //   * weights are pre-packed in MFMA A-fragment order (glass_pointwise_pack_weights) and stream L2 -> registers, 1 KiB
 //     coalesced per load, a k-tile ahead: no LDS traffic, no barrier for them;
 //   * v_mfma_f32_16x16x4_f32 with A = weights (rows = 16 output channels), B = pixels: a lane ends up with 4 consecutive
-//     channels of its pixel, so the epilogue is bias / ReLU / residual on registers and 16-byte row stores - no LDS
-//     transposition, no barrier;
+//     channels of its pixel per channel block - 8 consecutive ones over its two blocks, the packed order interleaves
+//     them - so the epilogue is bias / ReLU / residual on registers and 16-byte stores, 128 contiguous bytes per pixel and
+//     4 lanes: no LDS transposition, no barrier;
 //   * the input tile (16 PB pixels x 32 channels) goes global -> registers -> LDS (XOR-swizzled 16-byte slots,
 //     conflict-free ds_read_b128 = 4 k-steps x 2 channel blocks), double buffered, ONE barrier per k-tile;
 //   * block = 16 PB pixels x 128 channels, 4 wavefronts x 32 channels; 8 PB accumulator registers (128 for PB = 16), so
@@ -78,18 +79,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_f32(PwParams p) {
     xoff[i] = off;
   }
   float4 xreg[XL];
+  auto load_x1 = [&](int i, int kt) {
+    xreg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[i], kt * (PK * 4), 0));
+  };
   auto load_x = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < XL; ++i)
-      xreg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[i], kt * (PK * 4), 0));
+    for (int i = 0; i < XL; ++i) load_x1(i, kt);
   };
   // X[stage][pixel][32]: 128-byte rows, consecutive pixels alternate bank halves; slot ^= (pixel/2)%8 (see winograd43.hip)
+  auto store_x1 = [&](int i, int stage) {
+    const int px = prow + 32 * i;
+    *reinterpret_cast<float4*>(smem + stage * XS + px * PK + ((chunk ^ ((px >> 1) & 7)) * 4)) = xreg[i];
+  };
   auto store_x = [&](int stage) {
 #pragma unroll
-    for (int i = 0; i < XL; ++i) {
-      const int px = prow + 32 * i;
-      *reinterpret_cast<float4*>(smem + stage * XS + px * PK + ((chunk ^ ((px >> 1) & 7)) * 4)) = xreg[i];
-    }
+    for (int i = 0; i < XL; ++i) store_x1(i, stage);
   };
 
   // ---- MFMA role: wave wv owns channels n0 + 32 wv + [0, 32) for all PX pixels ----
@@ -104,14 +108,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_f32(PwParams p) {
   const unsigned a_voff = (unsigned)lane * 16u;
   f32x4 aq[2][2][2];                          // [k-tile parity][half][cb]
   // packed U: [tile_n][kt][wave][half][cb] chunks of 1 KiB (64 lanes x float4)
+  auto load_a1 = [&](int j, int kt, int par) {         // j = 2 half + cb
+    const int base = (((tile_n * p.nk + kt) * 4 + wv) * 4 + j) * 1024;
+    aq[par][j >> 1][j & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, base, 0));
+  };
   auto load_a = [&](int kt, int par) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const int base = ((((tile_n * p.nk + kt) * 4 + wv) * 2 + h) * 2 + cb) * 1024;
-        aq[par][h][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, base, 0));
-      }
+    for (int j = 0; j < 4; ++j) load_a1(j, kt, par);
   };
 
   load_x(0);
@@ -121,27 +124,33 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_f32(PwParams p) {
 
   // one k-tile; PAR = kt & 1 is a compile-time constant (the loop below is unrolled by two) so that the weight-fragment
   // ring and the LDS stage are statically indexed registers / addresses
+  // The issue order is pinned (sched_barrier): left alone the compiler waits for each LDS read right after issuing it and
+  // sinks the global loads to the end of the k-tile.  The B operand of group g + 1 is read while group g's 8 MFMAs run; the
+  // 4 weight and XL input loads of the next k-tile go out with the first groups and are written to the other LDS stage
+  // (last read in the previous k-tile, before its barrier) with the last groups: only the barrier separates two k-tiles.
   auto ktile = [&](int kt, auto par_) {
     constexpr int PAR = decltype(par_)::value;
     const int ktn = kt + 1 < p.nk ? kt + 1 : kt;     // clamped: a harmless re-read keeps the loop one block
-    load_x(ktn);
-    load_a(ktn, PAR ^ 1);
     f32x4 vq[2];
     vq[0] = *reinterpret_cast<const f32x4*>(vb[0] + PAR * XS);
     static_for<2 * PB>([&](auto g_) {               // group g = (half, pixel block): one LDS read, 8 MFMAs
       constexpr int g = decltype(g_)::value;
       constexpr int h = g / PB, pb = g % PB;
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (g + 1 < 2 * PB) {
         constexpr int h1 = (g + 1) / PB, pb1 = (g + 1) % PB;
         vq[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(vb[h1] + PAR * XS + pb1 * 16 * PK);
       }
+      if constexpr (g < XL) load_x1(g, ktn);
+      if constexpr (g < 4) load_a1(g, ktn, PAR ^ 1);
+      if constexpr (g >= 2 * PB - XL) store_x1(g - (2 * PB - XL), PAR ^ 1);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
           acc[pb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4p(aq[PAR][h][cb], s), comp4p(vq[g & 1], s), acc[pb][cb], 0, 0, 0);
     });
-    store_x(PAR ^ 1);                               // stage PAR^1 was last read in k-tile kt-1, before that tile's barrier
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   };
   for (int kt = 0; kt < p.nk; kt += 2) {
@@ -149,54 +158,69 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_f32(PwParams p) {
     if (kt + 1 < p.nk) ktile(kt + 1, ic<1>{});
   }
 
-  // ---- epilogue: lane = (pixel 16 pb + vj, channels n0 + 32 wv + 16 cb + 4 kg + e) ----
+  // ---- epilogue: lane = (pixel 16 pb + vj, channels n0 + 32 wv + 8 kg + 4 cb + e): the packed order interleaves the two
+  // channel blocks, so a lane holds 8 consecutive channels and 4 lanes complete a 128-byte line of their pixel ----
   __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_mode != 0 ? p.res : p.y), 0,
                                                                  (int)(p.res_mode != 0 ? p.r_bytes : 0u), 0x00020000);
-  const int cbase = n0 + 32 * wv + 4 * kg;       // + 16 cb: one store instruction covers 64 contiguous bytes per pixel
+  const int cbase = n0 + 32 * wv + 8 * kg;       // + 4 cb
   const unsigned ldy4 = (unsigned)p.ldy * 4u, ldr4 = (unsigned)p.ldr * 4u;
   const float lo2 = p.relu == 2 ? 0.f : __builtin_nanf(""), lo1 = p.relu == 1 ? 0.f : __builtin_nanf("");
   f32x4 bv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   if (p.bias != nullptr) {
     bv[0] = *reinterpret_cast<const f32x4*>(p.bias + cbase);
-    bv[1] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 16);
+    bv[1] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4);
   }
   const int HoWo2 = (p.Ho >> 1) * (p.Wo >> 1);
+  // compile-time residual variants, and the residual loads of a batch of pixel blocks all go out before its first store:
+  // a load issued after a store waits for it (one in-order counter), which serialised the pixel blocks of a wavefront
+  auto epilogue = [&](auto res_c) {
+    constexpr bool RES = decltype(res_c)::value != 0;
+    constexpr int PBB = PB < 8 ? PB : 8;
 #pragma unroll
-  for (int pb = 0; pb < PB; ++pb) {
-    const int m = m0 + 16 * pb + vj;
-    const bool ok = m < p.M;
-    const unsigned yo = ok ? (unsigned)m * ldy4 + (unsigned)(p.ycoff + cbase) * 4u : OOB;
-    f32x4 r[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (p.res_mode != 0) {
-      unsigned ro = OOB;
-      if (ok) {
-        int rp = m;
-        if (p.res_mode == 2) {                      // x2 nearest-upsampled residual [N, Ho/2, Wo/2, ldr]
-          const int n = fast_div(m, HoWo, p.magic_hw);
-          const int rem = m - n * HoWo;
-          const int ho = fast_div(rem, p.Wo, p.magic_w);
-          const int wo = rem - ho * p.Wo;
-          rp = n * HoWo2 + (ho >> 1) * (p.Wo >> 1) + (wo >> 1);
+    for (int b0 = 0; b0 < PB; b0 += PBB) {
+      unsigned yo[PBB];
+      f32x4 rq[RES ? PBB : 1][2];
+#pragma unroll
+      for (int i = 0; i < PBB; ++i) {
+        const int m = m0 + 16 * (b0 + i) + vj;
+        const bool ok = m < p.M;
+        yo[i] = ok ? (unsigned)m * ldy4 + (unsigned)(p.ycoff + cbase) * 4u : OOB;
+        if constexpr (RES) {
+          unsigned ro = OOB;
+          if (ok) {
+            int rp = m;
+            if (p.res_mode == 2) {                      // x2 nearest-upsampled residual [N, Ho/2, Wo/2, ldr]
+              const int n = fast_div(m, HoWo, p.magic_hw);
+              const int rem = m - n * HoWo;
+              const int ho = fast_div(rem, p.Wo, p.magic_w);
+              const int wo = rem - ho * p.Wo;
+              rp = n * HoWo2 + (ho >> 1) * (p.Wo >> 1) + (wo >> 1);
+            }
+            ro = (unsigned)rp * ldr4 + (unsigned)cbase * 4u;
+          }
+          rq[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro, 0, 0));
+          rq[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro, 16, 0));
         }
-        ro = (unsigned)rp * ldr4 + (unsigned)cbase * 4u;
       }
-      r[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro, 0, 0));
-      r[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro, 64, 0));
-    }
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      f32x4 v = acc[pb][cb] + bv[cb];
-      v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
-      if (p.res_mode != 0) v = v + r[cb];
-      v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo, cb * 64, 0);
+      for (int i = 0; i < PBB; ++i) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          f32x4 v = acc[b0 + i][cb] + bv[cb];
+          v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
+          if constexpr (RES) v = v + rq[i][cb];
+          v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[i], cb * 16, 0);
+        }
+      }
     }
-  }
+  };
+  if (p.res_mode != 0) epilogue(ic<1>{}); else epilogue(ic<0>{});
 }
 
 // W [Cout][1][1][Cin] -> [cout/128][cin/32][wave][half][cb][lane][s]  with
-//   cout = 128 tn + 32 wave + 16 cb + 4 ((lane&15)>>2) + (lane&3),   cin = 32 kt + 16 half + 4 (lane>>4) + s
+//   cout = 128 tn + 32 wave + 8 ((lane&15)>>2) + 4 cb + (lane&3),   cin = 32 kt + 16 half + 4 (lane>>4) + s
 __global__ void pw_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
   const long total = (long)Cout * Cin;
   const int nk = Cin / PK;
@@ -209,7 +233,7 @@ __global__ void pw_pack_weights_kernel(const float* __restrict__ w, float* __res
     const int wave = (int)(r & 3); r >>= 2;
     const int kt = (int)(r % nk);
     const int tn = (int)(r / nk);
-    const int co = tn * PN + 32 * wave + 16 * cb + 4 * ((lane & 15) >> 2) + (lane & 3);
+    const int co = tn * PN + 32 * wave + 8 * ((lane & 15) >> 2) + 4 * cb + (lane & 3);
     const int ci = kt * PK + 16 * half + 4 * (lane >> 4) + s;
     u[o] = w[(long)co * Cin + ci];
   }

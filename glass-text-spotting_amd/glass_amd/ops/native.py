@@ -264,9 +264,11 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                                           c_void_p(_dev(residual, "residual") if residual is not None else None),
                                           c_void_p(_dev(out, "out")), c_void_p(stream_handle())), "glass_conv2d_nhwc_f16")
         return out
-    # the weight-streaming 1x1 kernel wins where the k-loop is long enough and the grid fills the chip (measured,
-    # scripts/bench_conv.py: 256->1024 and 256->256 x1.11, 1024->256 x1.05; 64->256 x0.90, 512->2048 @32x32 x0.91,
-    # 512->128 x0.96)
+    # the weight-streaming 1x1 kernel on the wide layers with long k-loops.  Layer by layer (scripts/bench_conv.py) it is
+    # ahead for every Cin >= 256 (256->1024 and 256->256 x1.08, 1024->256 x1.09, 512->128 x1.11, 512->2048 @32x32 x1.07;
+    # behind on 128->512 x0.92 and 64->256 x0.87), but routing the narrow / small ones to it (Cout 128, 8192-pixel maps)
+    # LOWERS the end-to-end rate: 274.1 images/s with this rule, 271 without the kernel, 267 with "Cin >= 256, >= 8192
+    # pixels" (three alternating runs each, same box)
     if (winograd is None and _WINO["pw"] and KH == 1 and KW == 1 and (_WINO["pw"] == "all" or (Cin >= 256 and Cout >= 256 and N * Ho * Wo >= 16384))
             and lib().glass_pointwise_supported(ctypes.byref(d))):
         u = _winograd_weights(w, "pw")
