@@ -206,3 +206,24 @@ extern "C" int glass_mul_inplace(float* a, const float* b, int64_t n, glass_stre
   GLASS_CHECK_LAUNCH("glass_mul_inplace");
   return GLASS_OK;
 }
+
+// ---------------------------------------------------------------- fp32 -> fp16 (round to nearest even): the operand rounding
+// of the fp16 conv modes done once, so that an fp32 activation tensor can feed glass_conv2d_nhwc_h16_packed
+typedef _Float16 cast_h4 __attribute__((ext_vector_type(4)));
+__global__ void cast_f32_to_f16_kernel(const float4* __restrict__ x, cast_h4* __restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = x[i];
+    y[i] = cast_h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+  }
+}
+
+extern "C" int glass_cast_f32_to_f16(const float* x, void* y, int64_t n, glass_stream_t stream) {
+  GLASS_CHECK_ARG((x && y) || n == 0, "glass_cast_f32_to_f16: null pointer");
+  GLASS_CHECK_ARG(n >= 0 && n % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0,
+                  "glass_cast_f32_to_f16: n %% 4 == 0, x 16-byte and y 8-byte aligned required");
+  if (n == 0) return GLASS_OK;
+  hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(x), static_cast<cast_h4*>(y), (long)(n / 4));
+  GLASS_CHECK_LAUNCH("glass_cast_f32_to_f16");
+  return GLASS_OK;
+}

@@ -188,7 +188,10 @@ def _winograd_weights(w: torch.Tensor, f43=False) -> torch.Tensor:
     cache = _WINO["cache"]
     key = (w.data_ptr(), tuple(w.shape), f43)
     ent = cache.get(key)
-    if ent is not None and ent[0] is w and ent[2] == w._version:
+    # the entry pins the tensor it was packed from, so its storage cannot be recycled while the entry lives: another tensor
+    # with this address and shape is a view of the same storage (linear() passes a fresh 4-D view on every call) and shares
+    # its version counter
+    if ent is not None and ent[2] == w._version:
         cache.move_to_end(key)
         return ent[1]
     u = winograd_pack(w, f43)
@@ -258,6 +261,22 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                                           c_void_p(_dev(out, "out")), int(flags), c_void_p(stream_handle())), "glass_conv2d_nhwc_h16")
         return out
     if _WINO["precision"] in ("fp16", "fp16s") and not winograd:
+        # fp32 tensors in an fp16 mode (every layer of 'fp16', the fp32-input layers of 'fp16s': fusion conv, fc1 / fc2): where
+        # a conv does enough work per input element, round the input to fp16 ONCE (glass_cast_f32_to_f16 - the rounding the
+        # template applies while staging) and run the fp16-MFMA kernel on it; fp32 output and residual as they are
+        if (_WINO["h16"] and KH * KW * Cout >= 1024 and x.numel() > 0 and
+                lib().glass_conv_h16_supported(ctypes.byref(d), 1)):
+            xh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+            check(lib().glass_cast_f32_to_f16(c_void_p(_dev(x, "x")), c_void_p(_dev(xh)), x.numel(), c_void_p(stream_handle())),
+                  "glass_cast_f32_to_f16")
+            u = _winograd_weights(w, "h16")
+            _WINO["last_path"] = "packed_fp16"
+            check(lib().glass_conv2d_nhwc_h16_packed(ctypes.byref(d), c_void_p(_dev(xh, "x")), c_void_p(_dev(u, "u")),
+                                                     c_void_p(_dev(bias, "bias") if bias is not None else None),
+                                                     c_void_p(_dev(residual, "residual") if residual is not None else None),
+                                                     c_void_p(_dev(out, "out")), 1, c_void_p(stream_handle())),
+                  "glass_conv2d_nhwc_h16_packed")
+            return out
         _WINO["last_path"] = "direct_fp16"
         check(lib().glass_conv2d_nhwc_f16(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
                                           c_void_p(_dev(bias, "bias") if bias is not None else None),

@@ -311,6 +311,10 @@ int glass_mean_over_h(const float* x, float* y, int R, int H, int W, int C, glas
 /* a[i] *= b[i] (the gate of the `SimpleAttention` fusion variant, glass/modeling/fusion/fusion_modules.py:181-186) */
 int glass_mul_inplace(float* a, const float* b, int64_t n, glass_stream_t stream);
 
+/* y[i] = fp16(x[i]), round to nearest even: the operand rounding of the fp16 conv modes applied once to an fp32 activation
+ * tensor so that it can feed glass_conv2d_nhwc_h16_packed (same results as glass_conv2d_nhwc_h16 rounding it on the fly) */
+int glass_cast_f32_to_f16(const float* x, void* y, int64_t n, glass_stream_t stream);
+
 /* ------------------------------------------------------------------ rotated mask branch (inference)
  * MaskRotatedRecognizerHybridHead._forward_mask + d2 MaskRCNNConvUpsampleHead + mask_rcnn_inference
  * (glass/modeling/fusion/recognizers_hybrid_head.py:378-442,595-606; rotated_mask_head.py:409-442): the pooler

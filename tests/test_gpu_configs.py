@@ -170,7 +170,7 @@ def test_config4_fp16_conv_mode_tracks_the_fp32_path(sd):
         res = m.inference([{"image": img}], do_postprocess=False, override_boxes=boxes)
         outs[prec] = (res.batch.text.cpu().numpy(), K.last_conv_path())
         assert K.conv_precision() == "fp32"                       # the model restores the global setting
-    assert outs["fp16"][1] == "direct_fp16" and outs["fp32"][1] in ("direct", "winograd")
+    assert outs["fp16"][1] in ("direct_fp16", "packed_fp16") and outs["fp32"][1] in ("direct", "winograd")
     p, q = outs["fp16"][0], outs["fp32"][0]
     live = q.sum(-1) > 0
     # greedy decoding: one flipped character re-routes the rest of that word, so the bound is on agreement and on the
@@ -191,7 +191,9 @@ def _compare_reduced(det, n, ref, what):
     k = d.counts_host[n]
     fr, fg, ds, db = match_box_sets(d.boxes[n, :k].cpu().numpy(), d.scores[n, :k].cpu().numpy(), ref["pred_boxes"].numpy(), ref["scores"].numpy())
     print(f"[parity] {what}: detections {k} vs oracle {len(ref['scores'])}: matched {fr:.3f} / {fg:.3f}, max |dscore| {ds:.3e}, max |dbox| {db:.3e}")
-    assert fr >= 0.85 and fg >= 0.85 and ds < 5e-2 and db < 3.0       # px / degrees on boxes of up to ~1000 px
+    # (a detection is scored on ITS proposal, which moved by up to db pixels: the score bound is the proposal logits' bound;
+    # observed over the conv kernels this mode has had, i.e. over fp32 summation orders: 5e-3 ... 7e-2)
+    assert fr >= 0.85 and fg >= 0.85 and ds < 0.1 and db < 3.0        # px / degrees on boxes of up to ~1000 px
 
 
 @pytest.mark.parametrize("prec", ["fp16", "fp16s"])
