@@ -15,7 +15,7 @@
 //     order interleaves the two channel blocks), so the epilogue is bias / ReLU / residual on registers and one 16-byte
 //     store per pixel (fp16 out) - no LDS transposition;
 //   * block = 256 pixels x 128 channels (4 wavefronts x 32 channels) or 256 x 64 (2 x 2 wavefronts of 128 pixels x 32
-//     channels) or the 128-pixel halves of those; <= 128 accumulator registers, TWO workgroups per CU.
+//     channels) or the 128- / 64-pixel fractions of those; <= 128 accumulator registers, TWO workgroups per CU.
 // k-tile order is (channel block, tap) with the tap fastest, so the nine shifted reads of a channel block hit L2 / L1.
 // Results: fp16?(act(sum over fp16(x) fp16(w) in fp32 + bias [+ residual])) - the same arithmetic as
 // glass_conv2d_nhwc_h16 up to fp32 summation order (tests/test_gpu_ops.py compares the two and the fp64 reference).
@@ -383,9 +383,11 @@ extern "C" int glass_conv2d_nhwc_h16_packed(const glass_conv_desc* d, const void
   p.magic_w = (unsigned)(0x100000000ULL / (unsigned long long)d->Wo);
   const int PN = h16_block_channels(d->Cout);
   p.tiles_n = d->Cout / PN;
-  // 256-pixel blocks when they still give every CU ~1.5 workgroups, else 128-pixel blocks
+  // 256-pixel blocks when they still give every CU ~1.5 workgroups, else 128-pixel blocks, 64-pixel ones when even those
+  // leave a quarter of the CUs idle (the linear layers: fc1 / fc2 at M = 800)
   const bool big = (long)cdiv(p.M, 256) * p.tiles_n >= 384;
-  p.tiles_m = cdiv(p.M, big ? 256 : 128);
+  const bool tiny = !big && (long)cdiv(p.M, 128) * p.tiles_n < 192;
+  p.tiles_m = cdiv(p.M, big ? 256 : tiny ? 64 : 128);
   const long nblk = (long)p.tiles_m * p.tiles_n;
   GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv2d_nhwc_h16_packed: bad grid");
   const dim3 grid((unsigned)nblk), block(256);
@@ -431,10 +433,12 @@ extern "C" int glass_conv2d_nhwc_h16_packed(const glass_conv_desc* d, const void
 #endif
   if (PN == 128) {
     if (big) hipLaunchKernelGGL((conv_h16_kernel<16, 1>), grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((conv_h16_kernel<8, 1>), grid, block, 0, (hipStream_t)stream, p);
+    else if (!tiny) hipLaunchKernelGGL((conv_h16_kernel<8, 1>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_h16_kernel<4, 1>), grid, block, 0, (hipStream_t)stream, p);
   } else {
     if (big) hipLaunchKernelGGL((conv_h16_kernel<8, 2>), grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((conv_h16_kernel<4, 2>), grid, block, 0, (hipStream_t)stream, p);
+    else if (!tiny) hipLaunchKernelGGL((conv_h16_kernel<4, 2>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv_h16_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, p);
   }
   GLASS_CHECK_LAUNCH("glass_conv2d_nhwc_h16_packed");
   return GLASS_OK;

@@ -264,7 +264,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         # fp32 tensors in an fp16 mode (every layer of 'fp16', the fp32-input layers of 'fp16s': fusion conv, fc1 / fc2): where
         # a conv does enough work per input element, round the input to fp16 ONCE (glass_cast_f32_to_f16 - the rounding the
         # template applies while staging) and run the fp16-MFMA kernel on it; fp32 output and residual as they are
-        if (_WINO["h16"] and KH * KW * Cout >= 1024 and x.numel() > 0 and
+        if (_WINO["h16"] and KH * KW * Cout >= 512 and x.numel() > 0 and
                 lib().glass_conv_h16_supported(ctypes.byref(d), 1)):
             xh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
             check(lib().glass_cast_f32_to_f16(c_void_p(_dev(x, "x")), c_void_p(_dev(xh)), x.numel(), c_void_p(stream_handle())),

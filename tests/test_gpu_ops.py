@@ -437,7 +437,7 @@ def test_conv_fp16_mode_equals_conv_of_fp16_rounded_operands(case):
                           residual=None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev), res_mode=res_mode)
         # layers with Cin, Cout multiples of 64 and enough work per input element: input rounded once (glass_cast_f32_to_f16)
         # + the fp16-MFMA kernel; the others: the fp32 template rounding its operands as it stages them.  Same arithmetic.
-        packed = Cin % 64 == 0 and Cout % 64 == 0 and k[0] * k[1] * Cout >= 1024
+        packed = Cin % 64 == 0 and Cout % 64 == 0 and k[0] * k[1] * Cout >= 512
         assert K.last_conv_path() == ("packed_fp16" if packed else "direct_fp16")
     finally:
         K.set_conv_precision(prev)
@@ -514,9 +514,12 @@ H16_CASES = [
     (3, 7, 9, 64, 40, (1, 1), (1, 1), (0, 0), 2, 0, True, True, False),           # ragged rows and channel block (vector epilogue off: Cout % 4 == 0 but 40)
     (2, 8, 32, 256, 256, (2, 1), (2, 1), (0, 0), 1, 0, True, True, False),
     (1, 12, 20, 96, 136, (1, 1), (1, 1), (0, 0), 1, 1, True, False, True),        # fp16 residual into an fp32 output
-    # the four shapes of conv_h16_kernel: 256 x 128 / 128 x 128 / 256 x 64 / 128 x 64 pixel x channel blocks
-    (8, 64, 64, 64, 384, (3, 3), (1, 1), (1, 1), 1, 1, True, True, True),
-    (8, 64, 60, 128, 192, (3, 3), (1, 1), (1, 1), 2, 1, True, True, False),
+    # the six shapes of conv_h16_kernel: 256 / 128 / 64 pixels x 128 / 64 channels per block (the small cases above and
+    # below take the 64-pixel ones)
+    (8, 64, 64, 64, 384, (3, 3), (1, 1), (1, 1), 1, 1, True, True, True),         # 256 x 128
+    (2, 64, 64, 64, 384, (3, 3), (1, 1), (1, 1), 1, 0, True, True, False),        # 128 x 128
+    (8, 64, 64, 128, 192, (1, 1), (1, 1), (0, 0), 0, 1, True, False, True),       # 256 x 64
+    (8, 64, 60, 128, 192, (3, 3), (1, 1), (1, 1), 2, 1, True, True, False),       # 128 x 64
     (2, 13, 11, 192, 64, (3, 3), (2, 2), (1, 1), 1, 0, True, False, False),       # ragged last block, stride 2 with padding
     (1, 9, 9, 64, 128, (5, 5), (1, 1), (2, 2), 0, 0, True, True, False),          # 25 taps, most of them padding at the rim
     (4, 1, 1, 1024, 256, (1, 1), (1, 1), (0, 0), 1, 0, True, False, False),       # a linear layer: 4 pixels in a 128-pixel block
