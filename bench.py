@@ -262,7 +262,11 @@ def main():
         else:
             step_inputs = inputs
         if args.workload == "backbone":                           # BASELINE configs[1]: trunk + FPN only
-            model.backbone.forward_nhwc(il.nhwc4)
+            prev = K.set_conv_precision(args.precision)           # (inference_g scopes this itself; no yield in between here)
+            try:
+                model.backbone.forward_nhwc(il.nhwc4)
+            finally:
+                K.set_conv_precision(prev)
             return torch.zeros((B, 1), device=dev)
             yield                                                 # pragma: no cover (makes this a generator)
         out = yield from model.inference_g(step_inputs, override_boxes=boxes)   # list[{"instances": Instances}] (views)
@@ -424,10 +428,13 @@ def main():
                      ("f16 operands, f32 accumulate/storage (reduced precision: not the headline)" if args.precision == "fp16" else
                       "f16 operands AND f16 activation storage on the conv path, f32 accumulate (reduced precision: not the headline)"),
             "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[2]: backbone + RotatedROIAlign + recognition head, "
-                                    f"{args.rois} RoIs/img, bs={B}/GPU, {args.side}x{args.side} (padded to /32), fp32")
-                       if args.workload == "e2e" else
-                       f"BASELINE.json configs[1]: ResNet50-FPN backbone only, bs={B}/GPU, {args.side}x{args.side}, fp32",
+            "config": {"workload": ((("BASELINE.json configs[2]" if (args.side, args.rois) == (SIDE, ROIS) else
+                                      "the pipeline of BASELINE.json configs[2] at another shape (configs[4]: 1333-long-side, 100 RoIs)")
+                                     + ": backbone + RotatedROIAlign + recognition head, "
+                                     f"{args.rois} RoIs/img, bs={B}/GPU, {args.side}x{args.side} (padded to /32), {args.precision}")
+                                    if args.workload == "e2e" else
+                                    f"BASELINE.json configs[1]: ResNet50-FPN backbone only, bs={B}/GPU, {args.side}x{args.side}, "
+                                    f"{args.precision}"),
                        "images_per_gpu_per_step": B, "rois_per_image": args.rois, "proposals_per_image": 100,
                        "weights": "random-init (seed 1234), reference architecture",
                        "parallelism": f"image-shard x{world}, 1 all_gather of result records/step",
