@@ -447,6 +447,30 @@ def test_conv_fp16_mode_equals_conv_of_fp16_rounded_operands(case):
     assert float((got - ref).abs().max()) <= 1e-5 * scale
 
 
+def test_cast_f32_to_f16_is_round_to_nearest_even():
+    """glass_cast_f32_to_f16 (the operand rounding of the fp16 conv modes applied once): bit-identical to torch's .half() -
+    ties to even, subnormals, overflow to inf, signed zeros, NaN stays NaN"""
+    import ctypes
+    from glass_amd.ops import native as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(4096, generator=g) * 3, torch.randn(2048, generator=g) * 1e-5, torch.randn(1024, generator=g) * 7e4,
+                   torch.tensor([0.0, -0.0, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 65504.0, 65520.0, -65520.0, 6e-8, 2.98e-8, 2.99e-8,
+                                 float("inf"), -float("inf")])])
+    x = torch.cat([x, torch.zeros((-x.numel()) % 4)])
+    xd = x.to(dev)
+    y = torch.empty(x.shape, dtype=torch.float16, device=dev)
+    K.check(K.lib().glass_cast_f32_to_f16(ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(y.data_ptr()), x.numel(),
+                                          ctypes.c_void_p(K.stream_handle())), "glass_cast_f32_to_f16")
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu().view(torch.int16), x.half().view(torch.int16))
+    nan = torch.full((4,), float("nan"), device=dev)
+    yn = torch.empty((4,), dtype=torch.float16, device=dev)
+    K.check(K.lib().glass_cast_f32_to_f16(ctypes.c_void_p(nan.data_ptr()), ctypes.c_void_p(yn.data_ptr()), 4,
+                                          ctypes.c_void_p(K.stream_handle())), "glass_cast_f32_to_f16")
+    assert bool(torch.isnan(yn.float()).all())
+
+
 def test_upload_is_stream_ordered_and_exact():
     """ops.native.upload (pinned staging, non-blocking copy): the values arrive intact even when the staging tensor is
     dropped immediately and many uploads are in flight behind a long-running kernel"""
