@@ -236,6 +236,17 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
                  res_mode if residual is not None else 0, residual.shape[-1] if residual is not None else 0)
     if residual is not None:
         _fhc(residual, "residual")
+    def launch(entry: str, path: str, xt: torch.Tensor, weights: torch.Tensor, flags: Optional[int] = None) -> torch.Tensor:
+        """one conv entry of the library: (desc, x, w | packed weights, bias, residual, y[, flags], stream)"""
+        _WINO["last_path"] = path
+        args = [ctypes.byref(d), c_void_p(_dev(xt, "x")), c_void_p(_dev(weights, "w")),
+                c_void_p(_dev(bias, "bias") if bias is not None else None),
+                c_void_p(_dev(residual, "residual") if residual is not None else None), c_void_p(_dev(out, "out"))]
+        if flags is not None:
+            args.append(int(flags))
+        check(getattr(lib(), entry)(*args, c_void_p(stream_handle())), entry)
+        return out
+
     any_half = x.dtype == torch.float16 or out.dtype == torch.float16 or (residual is not None and residual.dtype == torch.float16)
     if any_half:
         if _WINO["precision"] != "fp16s" or winograd:
@@ -246,20 +257,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         # pre-rounded and packed once); everything else - fp32 entries, the 4/16/32-channel first layers, the narrow heads -
         # stays on the fp32 template with fp16 operands
         if _WINO["h16"] and lib().glass_conv_h16_supported(ctypes.byref(d), int(flags)):
-            u = _winograd_weights(w, "h16")
-            _WINO["last_path"] = "packed_fp16"
-            check(lib().glass_conv2d_nhwc_h16_packed(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
-                                                     c_void_p(_dev(bias, "bias") if bias is not None else None),
-                                                     c_void_p(_dev(residual, "residual") if residual is not None else None),
-                                                     c_void_p(_dev(out, "out")), int(flags), c_void_p(stream_handle())),
-                  "glass_conv2d_nhwc_h16_packed")
-            return out
-        _WINO["last_path"] = "direct_fp16"
-        check(lib().glass_conv2d_nhwc_h16(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
-                                          c_void_p(_dev(bias, "bias") if bias is not None else None),
-                                          c_void_p(_dev(residual, "residual") if residual is not None else None),
-                                          c_void_p(_dev(out, "out")), int(flags), c_void_p(stream_handle())), "glass_conv2d_nhwc_h16")
-        return out
+            return launch("glass_conv2d_nhwc_h16_packed", "packed_fp16", x, _winograd_weights(w, "h16"), flags)
+        return launch("glass_conv2d_nhwc_h16", "direct_fp16", x, w, flags)
     if _WINO["precision"] in ("fp16", "fp16s") and not winograd:
         # fp32 tensors in an fp16 mode (every layer of 'fp16', the fp32-input layers of 'fp16s': fusion conv, fc1 / fc2): where
         # a conv does enough work per input element, round the input to fp16 ONCE (glass_cast_f32_to_f16 - the rounding the
@@ -269,20 +268,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
             xh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
             check(lib().glass_cast_f32_to_f16(c_void_p(_dev(x, "x")), c_void_p(_dev(xh)), x.numel(), c_void_p(stream_handle())),
                   "glass_cast_f32_to_f16")
-            u = _winograd_weights(w, "h16")
-            _WINO["last_path"] = "packed_fp16"
-            check(lib().glass_conv2d_nhwc_h16_packed(ctypes.byref(d), c_void_p(_dev(xh, "x")), c_void_p(_dev(u, "u")),
-                                                     c_void_p(_dev(bias, "bias") if bias is not None else None),
-                                                     c_void_p(_dev(residual, "residual") if residual is not None else None),
-                                                     c_void_p(_dev(out, "out")), 1, c_void_p(stream_handle())),
-                  "glass_conv2d_nhwc_h16_packed")
-            return out
-        _WINO["last_path"] = "direct_fp16"
-        check(lib().glass_conv2d_nhwc_f16(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
-                                          c_void_p(_dev(bias, "bias") if bias is not None else None),
-                                          c_void_p(_dev(residual, "residual") if residual is not None else None),
-                                          c_void_p(_dev(out, "out")), c_void_p(stream_handle())), "glass_conv2d_nhwc_f16")
-        return out
+            return launch("glass_conv2d_nhwc_h16_packed", "packed_fp16", xh, _winograd_weights(w, "h16"), 1)
+        return launch("glass_conv2d_nhwc_f16", "direct_fp16", x, w)
     # the weight-streaming 1x1 kernel on the wide layers with long k-loops.  Layer by layer (scripts/bench_conv.py) it is
     # ahead for every Cin >= 256 (256->1024 and 256->256 x1.08, 1024->256 x1.09, 512->128 x1.11, 512->2048 @32x32 x1.07;
     # behind on 128->512 x0.92 and 64->256 x0.87), but routing the narrow / small ones to it (Cout 128, 8192-pixel maps)
@@ -290,14 +277,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     # pixels" (three alternating runs each, same box)
     if (winograd is None and _WINO["pw"] and KH == 1 and KW == 1 and (_WINO["pw"] == "all" or (Cin >= 256 and Cout >= 256 and N * Ho * Wo >= 16384))
             and lib().glass_pointwise_supported(ctypes.byref(d))):
-        u = _winograd_weights(w, "pw")
-        _WINO["last_path"] = "pointwise"
-        check(lib().glass_conv1x1_pointwise_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
-                                                 c_void_p(_dev(bias, "bias") if bias is not None else None),
-                                                 c_void_p(_dev(residual, "residual") if residual is not None else None),
-                                                 c_void_p(_dev(out, "out")), c_void_p(stream_handle())),
-              "glass_conv1x1_pointwise_nhwc")
-        return out
+        return launch("glass_conv1x1_pointwise_nhwc", "pointwise", x, _winograd_weights(w, "pw"))
     use_wino = _WINO["enabled"] if winograd is None else winograd
     if winograd is None and use_wino and KH == 3:
         # the Winograd kernel runs one 64-tile x 64-channel workgroup per CU: below ~96 workgroups (FPN p6, batch-2 res5)
@@ -305,33 +285,15 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
     f43 = winograd == "f43" or (winograd is None and _WINO["f43"] and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin))
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
-        u = _winograd_weights(w, True)
-        _WINO["last_path"] = "winograd43"
-        check(lib().glass_conv3x3_winograd43_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
-                                                  c_void_p(_dev(bias, "bias") if bias is not None else None),
-                                                  c_void_p(_dev(residual, "residual") if residual is not None else None),
-                                                  c_void_p(_dev(out, "out")), c_void_p(stream_handle())),
-              "glass_conv3x3_winograd43_nhwc")
-        return out
+        return launch("glass_conv3x3_winograd43_nhwc", "winograd43", x, _winograd_weights(w, True))
     if winograd == "f43":
         raise GlassLibraryError("winograd='f43' but glass_winograd43_supported() rejects this layer")
     if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
-        u = _winograd_weights(w)
-        _WINO["last_path"] = "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd"
-        check(lib().glass_conv3x3_winograd_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "u")),
-                                                c_void_p(_dev(bias, "bias") if bias is not None else None),
-                                                c_void_p(_dev(residual, "residual") if residual is not None else None),
-                                                c_void_p(_dev(out, "out")), c_void_p(stream_handle())),
-              "glass_conv3x3_winograd_nhwc")
-        return out
+        return launch("glass_conv3x3_winograd_nhwc",
+                      "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd", x, _winograd_weights(w))
     if winograd:
         raise GlassLibraryError("winograd=True but glass_winograd_supported() rejects this layer")
-    _WINO["last_path"] = "direct"
-    check(lib().glass_conv2d_nhwc(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(w, "w")),
-                                  c_void_p(_dev(bias, "bias") if bias is not None else None),
-                                  c_void_p(_dev(residual, "residual") if residual is not None else None),
-                                  c_void_p(_dev(out, "out")), c_void_p(stream_handle())), "glass_conv2d_nhwc")
-    return out
+    return launch("glass_conv2d_nhwc", "direct", x, w)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: int = 0,
