@@ -1,17 +1,28 @@
 // Rotated-box IoU on device: restatement of detectron2 v0.6 layers/csrc/box_iou_rotated/box_iou_rotated_utils.h
 // (CPU variant of the convex-hull sort), shared by the NMS, pairwise-IoU and post-processing kernels.
+// Contraction is OFF in every function of this file (`#pragma clang fp contract(off)`): d2's CPU op is compiled for baseline
+// x86-64, i.e. every product and sum of the cross / dot products is rounded separately; with hipcc's default (fused
+// multiply-add wherever it can) the near-degenerate cases - collinear edges, |det| ~ 1e-14 - took the other branch of the
+// algorithm's epsilon tests about twice as often as the CPU code does (tests/test_gpu_d_known_answers.py: shared-edge family).
 #pragma once
 #include "common.h"
 
 struct Pt { float x, y; };
 __device__ __forceinline__ Pt psub(Pt a, Pt b) { return Pt{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ float dot2(Pt a, Pt b) { return a.x * b.x + a.y * b.y; }
-__device__ __forceinline__ float cross2(Pt a, Pt b) { return a.x * b.y - b.x * a.y; }
+__device__ __forceinline__ float dot2(Pt a, Pt b) {
+#pragma clang fp contract(off)
+  return a.x * b.x + a.y * b.y;
+}
+__device__ __forceinline__ float cross2(Pt a, Pt b) {
+#pragma clang fp contract(off)
+  return a.x * b.y - b.x * a.y;
+}
 
 // box = (cx, cy, w, h) + half-extent cos/sin (cos(theta)*0.5, sin(theta)*0.5 computed in double like d2)
 struct RBox { float cx, cy, w, h, c2, s2; };
 
 __device__ __forceinline__ void rbox_vertices(float cx, float cy, const RBox& b, Pt* pts) {
+#pragma clang fp contract(off)
   pts[0].x = cx + b.s2 * b.h + b.c2 * b.w;
   pts[0].y = cy + b.c2 * b.h - b.s2 * b.w;
   pts[1].x = cx - b.s2 * b.h + b.c2 * b.w;
@@ -29,6 +40,7 @@ __device__ __forceinline__ bool hull_less(Pt A, Pt B) {
 }
 
 __device__ inline float rotated_iou(const RBox& r1, const RBox& r2) {
+#pragma clang fp contract(off)
   const float area1 = r1.w * r1.h, area2 = r2.w * r2.h;
   if (area1 < 1e-14f || area2 < 1e-14f) return 0.f;
   {

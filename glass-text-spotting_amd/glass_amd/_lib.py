@@ -36,6 +36,17 @@ class GlassLibraryError(RuntimeError):
     pass
 
 
+# Device code is compiled WITHOUT packed-f32 (v_pk_*_f32) and fma_mix instruction selection.  On MI355X / ROCm 7.2 a VOP3P
+# instruction whose low-result selector is non-zero (`v_pk_mul_f32 ... op_sel:[0,1]`, hipcc's code for float2 / float4
+# arithmetic that crosses halves) returns a wrong low half in lanes 48..63 whenever a wavefront of ANOTHER kernel issues a
+# double-rate f16 / bf16 MFMA on the same SIMD - i.e. whenever an fp16-mode step is in flight beside this one (DESIGN.md
+# "co-resident MFMA erratum"; scripts/micro/pk_vs_convh16.hip reproduces it without any code of this library).  No code
+# inside the victim kernel can prevent it, so the instruction class is not generated at all; tests/test_isa_guard.py
+# disassembles the built library and fails on any such instruction.  (The host pass prints "'-packed-fp32-ops' is not a
+# recognized feature for this target" - harmless: -Xclang reaches both passes.)
+DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
+
+
 def sources() -> List[str]:
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -45,6 +56,7 @@ def source_sha16() -> str:
     a profile was taken with (profiles/*_pmc_conv_summary.json records it; bench.py refuses stale counters)."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(DEVICE_FLAGS).encode())       # the flags change the code as much as the sources do
     for f in sorted(sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
@@ -55,7 +67,7 @@ def source_sha16() -> str:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into libglass_hip.so (in-tree)."""
     srcs = sources()
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h")) + [os.path.abspath(__file__)]
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -69,7 +81,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(o) and
                 all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):])):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *DEVICE_FLAGS, "-I", INCLUDE, "-I", CSRC, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -5,7 +5,8 @@ The reference loads a torch `.pth` `{"model": state_dict}` with d2 module names 
 This module accepts the same key set and produces, once at load time, the
 device tensors the kernels read:
   conv  [Cout,Cin,KH,KW] (+BN eval)  ->  w [Cout,KH,KW,Cin4] fp32 (BN scale folded, Cin padded
-                                         to a multiple of 4 with zeros), bias [Cout]
+                                         to a multiple of 4 with zeros), bias [Cout]; wrapped in a
+                                         ConvWeight together with its packed kernel forms (conv_weight)
   linear / recurrent                 ->  see `pack_kblocked` in ops/native.py
 All tensor arithmetic here is one-off load-time plumbing on CPU (float64 fold, fp32 store).
 """
@@ -41,8 +42,16 @@ def fold_conv(sd: Dict[str, torch.Tensor], conv: str, norm: Optional[str], devic
     cin4 = (cin + cin_pad - 1) // cin_pad * cin_pad
     out = torch.zeros((cout, kh, kw, cin4), dtype=torch.float32)
     out[..., :cin] = w.permute(0, 2, 3, 1).float()
-    return out.contiguous().to(device), (None if b is None else b.float().contiguous().to(device))
+    return conv_weight(out, device), (None if b is None else b.float().contiguous().to(device))
 
 
 def dev(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().float().contiguous().to(device)
+
+
+def conv_weight(w: torch.Tensor, device):
+    """[Cout,KH,KW,Cin] (conv) or [Nout,K] (linear) -> ops.native.ConvWeight on `device`: the raw fp32 tensor plus every
+    packed form the layer's kernels stream (Winograd U, pointwise / fp16 MFMA fragment order), built here, ONCE, for the conv
+    precision of the model being loaded (ops.native.packing_for).  CPU `device` (host-only tests): raw tensor only."""
+    from .ops import native as K
+    return K.prepare_conv_weights(dev(w, device))

@@ -15,7 +15,7 @@ import torch
 
 from ...utils.module import InferenceModule
 
-from ...checkpoint import dev, fold_conv
+from ...checkpoint import conv_weight, dev, fold_conv
 from ...ops import native as K
 from ...utils.registry import Registry
 
@@ -111,7 +111,7 @@ class Conv1x1(_CatFusionBase):
 
     def import_weights(self, sd, device, prefix: str) -> None:
         w = sd[prefix + "conv.weight"].float().reshape(self.out_channels, self.in_channels)
-        self.w = {"conv": dev(self._cols_to_interleaved(w).reshape(self.out_channels, 1, 1, self.in_channels), device)}
+        self.w = {"conv": conv_weight(self._cols_to_interleaved(w).reshape(self.out_channels, 1, 1, self.in_channels), device)}
 
     def forward_interleaved(self, x: torch.Tensor) -> torch.Tensor:
         return K.conv2d_nhwc(x, self.w["conv"], None)
@@ -145,7 +145,7 @@ class SimpleAttention(_CatFusionBase):
         wl_rows = torch.empty_like(wl)
         wl_rows[_interleaved_position(C)] = wl
         wc = self._cols_to_interleaved(sd[prefix + "conv.weight"].float().reshape(self.out_channels, C))
-        self.w = {"linear": dev(wl_rows.reshape(C, 1, 1, C), device), "conv": dev(wc.reshape(self.out_channels, 1, 1, C), device)}
+        self.w = {"linear": conv_weight(wl_rows.reshape(C, 1, 1, C), device), "conv": conv_weight(wc.reshape(self.out_channels, 1, 1, C), device)}
 
     def forward_interleaved(self, x: torch.Tensor) -> torch.Tensor:
         g = K.conv2d_nhwc(x, self.w["linear"], None)

@@ -59,9 +59,15 @@ class GeneralizedRCNN(InferenceModule):
         """d2-keyed state dict (what DetectionCheckpointer hands over) -> folded, re-laid device
         weights.  `roi_heads.mask_head.*` keys are ignored (mask branch off at inference)."""
         dev = self._device
-        self.backbone.import_weights(state_dict, dev, "backbone.")
-        self.proposal_generator.import_weights(state_dict, dev, "proposal_generator.")
-        self.roi_heads.import_weights(state_dict, dev, "roi_heads.")
+        # every conv / linear weight is re-laid AND packed for this model's conv precision here (checkpoint.conv_weight ->
+        # ops.native.prepare_conv_weights): the packed tensors are owned by the layers, so they are freed with the model,
+        # and ONE synchronisation at the end makes them visible to whatever streams the steps will run on
+        with K.packing_for(self.conv_precision):
+            self.backbone.import_weights(state_dict, dev, "backbone.")
+            self.proposal_generator.import_weights(state_dict, dev, "proposal_generator.")
+            self.roi_heads.import_weights(state_dict, dev, "roi_heads.")
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
         self._loaded = True
         return self
 

@@ -14,7 +14,7 @@ import torch
 
 from ...utils.module import InferenceModule
 
-from ...checkpoint import dev
+from ...checkpoint import conv_weight, dev
 from ...ops import native as K
 from ...utils.registry import Registry
 
@@ -40,7 +40,7 @@ class ASTER_V2(InferenceModule):
         self.w = {
             "sW": dev(K.pack_kblocked(f("attention_unit.sEmbed.weight")), device),
             "sB": dev(f("attention_unit.sEmbed.bias"), device),
-            "xW": dev(f("attention_unit.xEmbed.weight"), device),
+            "xW": conv_weight(f("attention_unit.xEmbed.weight"), device),
             "xB": dev(f("attention_unit.xEmbed.bias"), device),
             "wW": dev(f("attention_unit.wEmbed.weight").reshape(-1), device),
             "wB": dev(f("attention_unit.wEmbed.bias").reshape(-1), device),

@@ -10,7 +10,7 @@ import torch
 
 from ...utils.module import InferenceModule
 
-from ...checkpoint import dev
+from ...checkpoint import conv_weight, dev
 from ...ops import native as K
 from ...utils.registry import Registry
 
@@ -37,8 +37,8 @@ class BiLSTMBlockV2(InferenceModule):
             b = torch.cat([sd[q + "rnn.bias_ih_l0"] + sd[q + "rnn.bias_hh_l0"],
                            sd[q + "rnn.bias_ih_l0_reverse"] + sd[q + "rnn.bias_hh_l0_reverse"]], 0)
             w_hh = torch.stack([sd[q + "rnn.weight_hh_l0"].float(), sd[q + "rnn.weight_hh_l0_reverse"].float()], 0)
-            self.layers.append({"w_ih": dev(w_ih, device), "b": dev(b, device), "w_hh": dev(w_hh, device),
-                                "lin_w": dev(sd[q + "linear.weight"], device), "lin_b": dev(sd[q + "linear.bias"], device)})
+            self.layers.append({"w_ih": conv_weight(w_ih, device), "b": dev(b, device), "w_hh": dev(w_hh, device),
+                                "lin_w": conv_weight(sd[q + "linear.weight"], device), "lin_b": dev(sd[q + "linear.bias"], device)})
 
     def forward_nhwc(self, feats: torch.Tensor) -> torch.Tensor:
         """feats [R,H,W,C] -> [R,W,C]."""

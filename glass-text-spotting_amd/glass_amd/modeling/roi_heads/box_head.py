@@ -11,7 +11,7 @@ import torch
 
 from ...utils.module import InferenceModule
 
-from ...checkpoint import dev
+from ...checkpoint import conv_weight, dev
 from ...ops import native as K
 from ...structures.core import ShapeSpec
 from ...utils.registry import ROI_BOX_HEAD_REGISTRY
@@ -38,7 +38,7 @@ class FastRCNNConvFCHead(InferenceModule):
             w = sd[f"{prefix}fc{i}.weight"].float()
             if i == 1:
                 w = w.view(w.shape[0], C, H, W).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
-            self.fcs.append((dev(w, device), dev(sd[f"{prefix}fc{i}.bias"], device)))
+            self.fcs.append((conv_weight(w, device), dev(sd[f"{prefix}fc{i}.bias"], device)))
 
     def forward_nhwc(self, pooled: torch.Tensor) -> torch.Tensor:
         """pooled [R,7,7,256] NHWC -> [R,fc_dim]."""

@@ -17,7 +17,7 @@ import torch
 
 from ...utils.module import InferenceModule
 
-from ...checkpoint import dev
+from ...checkpoint import conv_weight, dev
 from ...ops import native as K
 from ...structures.core import Instances, RotatedBoxes
 
@@ -37,7 +37,7 @@ class RotatedFastRCNNOutputLayers(InferenceModule):
 
     def import_weights(self, sd, device, prefix: str) -> None:
         names = ("cls_score", "bbox_pred") + (("orientation_pred",) if self.orientation_on else ())
-        self.w = {"w": dev(torch.cat([sd[prefix + n + ".weight"] for n in names], 0), device),
+        self.w = {"w": conv_weight(torch.cat([sd[prefix + n + ".weight"] for n in names], 0), device),
                   "b": dev(torch.cat([sd[prefix + n + ".bias"] for n in names], 0), device)}
 
     def forward(self, x: torch.Tensor):

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import torch
 
-from ...checkpoint import dev
+from ...checkpoint import conv_weight, dev
 from ...ops import native as K
 from ...structures.core import ShapeSpec
 from ...utils.module import InferenceModule
@@ -38,14 +38,14 @@ class RotatedMaskRCNNConvUpsampleHead(InferenceModule):
         self.convs = []
         for k in range(1, self.num_conv + 1):
             w = sd[f"{prefix}mask_fcn{k}.weight"].float().permute(0, 2, 3, 1)          # [Cout,3,3,Cin]
-            self.convs.append((dev(w, device), dev(sd[f"{prefix}mask_fcn{k}.bias"], device)))
+            self.convs.append((conv_weight(w, device), dev(sd[f"{prefix}mask_fcn{k}.bias"], device)))
         wd = sd[prefix + "deconv.weight"].float()                                       # [Cin, Cout, 2, 2]
         cin, cout = wd.shape[0], wd.shape[1]
         w1 = wd.permute(2, 3, 1, 0).reshape(4 * cout, 1, 1, cin)                        # row = (a*2+b)*Cout + co
         b1 = sd[prefix + "deconv.bias"].float().repeat(4)
-        self.deconv = (dev(w1, device), dev(b1, device))
+        self.deconv = (conv_weight(w1, device), dev(b1, device))
         wp = sd[prefix + "predictor.weight"].float().permute(0, 2, 3, 1)                # [classes,1,1,C]
-        self.predictor = (dev(wp, device), dev(sd[prefix + "predictor.bias"], device))
+        self.predictor = (conv_weight(wp, device), dev(sd[prefix + "predictor.bias"], device))
 
     def layers_nhwc(self, pooled: torch.Tensor) -> torch.Tensor:
         """pooled [R,P,P,C] NHWC -> mask logits [R,2P,2P,classes]."""

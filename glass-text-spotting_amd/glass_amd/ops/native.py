@@ -81,12 +81,12 @@ def conv_out_size(H, W, KH, KW, stride, padding):
     return (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
 
 
-# Winograd F(2x2,3x3) weights, packed once per weight tensor (glass_winograd_pack_weights) the first time a
-# 3x3/stride-1 layer runs.  Keyed by the weight's storage address; the entry pins the weight tensor so the
-# address cannot be recycled, and is re-packed if the tensor was modified in place (_version).
-_WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "cache": collections.OrderedDict(), "max": 512,
+# Process-wide kernel routing switches (env GLASS_*: experiments / A-B runs).  Packed weights are NOT kept here: they belong
+# to the layer that owns them (class ConvWeight below, built once at load by prepare_conv_weights).
+_WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "on_the_fly": 0,
          "f43": os.environ.get("GLASS_WINOGRAD43", "1") != "0", "pw": {"0": False, "all": "all"}.get(os.environ.get("GLASS_POINTWISE", "1"), True),
-         "precision": os.environ.get("GLASS_CONV_PRECISION", "fp32"), "h16": os.environ.get("GLASS_CONV_H16", "1") != "0"}
+         "precision": os.environ.get("GLASS_CONV_PRECISION", "fp32"), "h16": os.environ.get("GLASS_CONV_H16", "1") != "0",
+         "load_precision": None}
 
 
 def set_conv_precision(precision: str) -> str:
@@ -184,35 +184,124 @@ def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int) -> bool:
     return waste <= 1.25 and blocks >= 192
 
 
-def _winograd_weights(w: torch.Tensor, f43=False) -> torch.Tensor:
-    cache = _WINO["cache"]
-    key = (w.data_ptr(), tuple(w.shape), f43)
-    ent = cache.get(key)
-    # the entry pins the tensor it was packed from, so its storage cannot be recycled while the entry lives: another tensor
-    # with this address and shape is a view of the same storage (linear() passes a fresh 4-D view on every call) and shares
-    # its version counter
-    if ent is not None and ent[2] == w._version:
-        cache.move_to_end(key)
-        return ent[1]
-    u = winograd_pack(w, f43)
-    torch.cuda.current_stream().synchronize()      # once per weight: other streams (pipelined steps) may use it next
-    cache[key] = (w, u, w._version)
-    if len(cache) > _WINO["max"]:
-        cache.popitem(last=False)
-    return u
+class ConvWeight:
+    """One conv / linear layer's weights as the kernels read them: `raw` [Cout,KH,KW,Cin] fp32 (what the implicit-GEMM kernel
+    takes) plus the packed forms the other kernels stream (`packs`: False -> F(2x2,3x3) U, True -> F(4x4,3x3) U, "pw" ->
+    fragment-ordered 1x1 weights, "h16" -> fp16 fragment-ordered weights), built ONCE by prepare_conv_weights when the
+    checkpoint is loaded and owned by the layer: they live and die with the model, no global cache, no first-launch
+    synchronisation, nothing keyed by a device address (checkpoint row)."""
+    __slots__ = ("raw", "packs")
+
+    def __init__(self, raw: torch.Tensor):
+        self.raw = _f32c(raw, "w")
+        self.packs = {}
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    @property
+    def device(self):
+        return self.raw.device
+
+    def nbytes(self) -> int:
+        return self.raw.numel() * 4 + sum(u.numel() * u.element_size() for u in self.packs.values())
 
 
-def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride=1, padding=0,
+class packing_for:
+    """`with packing_for(precision):` around a model's import_weights: prepare_conv_weights packs for THAT conv precision
+    ('fp32': Winograd / pointwise forms, 'fp16' / 'fp16s': the fp16 fragment form) and skips its per-call stream
+    synchronisation - the caller synchronises once when every layer is packed (GeneralizedRCNN.load_state_dict)."""
+
+    def __init__(self, precision: str):
+        if precision not in ("fp32", "fp16", "fp16s"):
+            raise GlassLibraryError(f"unknown conv precision {precision!r}")
+        self.precision = precision
+
+    def __enter__(self):
+        self.prev = _WINO["load_precision"]
+        _WINO["load_precision"] = self.precision
+        return self
+
+    def __exit__(self, *exc):
+        _WINO["load_precision"] = self.prev
+        return False
+
+
+def _probe_desc(Cout: int, KH: int, KW: int, Cin: int) -> ConvDesc:
+    """a small stride-1 'same' layer with these channel counts: what the *_supported() entry points need to say whether a
+    weight CAN take a kernel (map size and batch decide at launch whether it does)"""
+    ph, pw = KH // 2, KW // 2
+    return ConvDesc(1, 16, 16, Cin, Cout, KH, KW, 1, 1, ph, pw, 16 + 2 * ph - KH + 1, 16 + 2 * pw - KW + 1, Cin, Cout, 0, 1, 0, 0, 0)
+
+
+def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str) -> list:
+    """which packed forms a [Cout,KH,KW,Cin] weight can be asked for under `precision` (the routing of conv2d_nhwc)"""
+    L, d = lib(), _probe_desc(Cout, KH, KW, Cin)
+    kinds = []
+    if precision == "fp32":
+        if KH == 3 and KW == 3:
+            if L.glass_winograd_supported(ctypes.byref(d)):
+                kinds.append(False)
+            if L.glass_winograd43_supported(ctypes.byref(d)):
+                kinds.append(True)
+        if KH == 1 and KW == 1 and L.glass_pointwise_supported(ctypes.byref(d)):
+            kinds.append("pw")
+    elif Cin % 64 == 0 and L.glass_conv_h16_supported(ctypes.byref(d), 1):
+        kinds.append("h16")
+    return kinds
+
+
+def prepare_conv_weights(w: torch.Tensor, precision: Optional[str] = None) -> ConvWeight:
+    """w [Cout,KH,KW,Cin] (or [Nout,K] for a linear layer) fp32 on the device -> ConvWeight with every packed form its layer
+    can be routed to under `precision` (default: the enclosing packing_for(), else the current conv precision).  Load-time
+    plumbing: ~10 pack kernels per MB of weights, once per model."""
+    if isinstance(w, ConvWeight):
+        return w
+    if w.dim() == 2:
+        w = w.view(w.shape[0], 1, 1, w.shape[1])
+    cw = ConvWeight(w)
+    in_load = _WINO["load_precision"] is not None
+    precision = precision or _WINO["load_precision"] or _WINO["precision"]
+    Cout, KH, KW, Cin = w.shape
+    if w.is_cuda:
+        for kind in pack_kinds(Cout, KH, KW, Cin, precision):
+            cw.packs[kind] = winograd_pack(w, kind)
+        if cw.packs and not in_load:
+            torch.cuda.current_stream().synchronize()      # other streams (pipelined steps) may launch with it next
+    return cw
+
+
+def packs_on_the_fly() -> int:
+    """how many conv launches had to pack their weights at launch time (a raw tensor instead of a ConvWeight, or a ConvWeight
+    prepared for another precision): 0 on the model path - tests assert it"""
+    return _WINO["on_the_fly"]
+
+
+def _packed(w, wt: torch.Tensor, kind) -> torch.Tensor:
+    if isinstance(w, ConvWeight):
+        u = w.packs.get(kind)
+        if u is not None:
+            return u
+    # raw tensors (tests, micro-benchmarks) and layers prepared for another precision: pack for this launch only - same
+    # stream as the launch, so stream order is all the synchronisation it needs, and nothing outlives the call
+    _WINO["on_the_fly"] += 1
+    return winograd_pack(wt, kind)
+
+
+def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stride=1, padding=0,
                 relu: int = 0, residual: Optional[torch.Tensor] = None, res_mode: int = 0,
                 out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cstride: int = 1,
                 cin: Optional[int] = None, winograd: Optional[bool] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """y = act(conv(x, w) + bias [+ residual]).  x [N,H,W,ldx] NHWC, w [Cout,KH,KW,Cin].
+    """y = act(conv(x, w) + bias [+ residual]).  x [N,H,W,ldx] NHWC, w [Cout,KH,KW,Cin]: a ConvWeight (the model path: packed
+    forms built at load) or a plain device tensor (packed per launch where the chosen kernel needs it).
     3x3/stride 1/pad 1 layers that glass_winograd_supported() accepts go through the Winograd kernel
     (winograd=None: follow set_winograd() / set_winograd43(); True/False force F(2x2,3x3) on / off for this call,
     "f43" forces the F(4x4,3x3) kernel)."""
-    _fhc(x, "x"); _f32c(w, "w")
+    wt = w.raw if isinstance(w, ConvWeight) else _f32c(w, "w")
+    _fhc(x, "x")
     N, H, W, ldx = x.shape
-    Cout, KH, KW, Cin = w.shape
+    Cout, KH, KW, Cin = wt.shape
     if cin is not None and cin != Cin:
         raise GlassLibraryError(f"cin={cin} does not match weight Cin={Cin}")
     sh, sw = _pair(stride)
@@ -257,8 +346,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         # pre-rounded and packed once); everything else - fp32 entries, the 4/16/32-channel first layers, the narrow heads -
         # stays on the fp32 template with fp16 operands
         if _WINO["h16"] and lib().glass_conv_h16_supported(ctypes.byref(d), int(flags)):
-            return launch("glass_conv2d_nhwc_h16_packed", "packed_fp16", x, _winograd_weights(w, "h16"), flags)
-        return launch("glass_conv2d_nhwc_h16", "direct_fp16", x, w, flags)
+            return launch("glass_conv2d_nhwc_h16_packed", "packed_fp16", x, _packed(w, wt, "h16"), flags)
+        return launch("glass_conv2d_nhwc_h16", "direct_fp16", x, wt, flags)
     if _WINO["precision"] in ("fp16", "fp16s") and not winograd:
         # fp32 tensors in an fp16 mode (every layer of 'fp16', the fp32-input layers of 'fp16s': fusion conv, fc1 / fc2): where
         # a conv does enough work per input element, round the input to fp16 ONCE (glass_cast_f32_to_f16 - the rounding the
@@ -266,10 +355,10 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         if (_WINO["h16"] and KH * KW * Cout >= 512 and x.numel() > 0 and
                 lib().glass_conv_h16_supported(ctypes.byref(d), 1)):
             xh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-            check(lib().glass_cast_f32_to_f16(c_void_p(_dev(x, "x")), c_void_p(_dev(xh)), x.numel(), c_void_p(stream_handle())),
-                  "glass_cast_f32_to_f16")
-            return launch("glass_conv2d_nhwc_h16_packed", "packed_fp16", xh, _winograd_weights(w, "h16"), 1)
-        return launch("glass_conv2d_nhwc_f16", "direct_fp16", x, w)
+            check(lib().glass_cast_f32_to_f16(c_void_p(_dev(x, "x")), c_void_p(_dev(xh)), ctypes.c_int64(x.numel()),
+                                              c_void_p(stream_handle())), "glass_cast_f32_to_f16")
+            return launch("glass_conv2d_nhwc_h16_packed", "packed_fp16", xh, _packed(w, wt, "h16"), 1)
+        return launch("glass_conv2d_nhwc_f16", "direct_fp16", x, wt)
     # the weight-streaming 1x1 kernel on the wide layers with long k-loops.  Layer by layer (scripts/bench_conv.py) it is
     # ahead for every Cin >= 256 (256->1024 and 256->256 x1.08, 1024->256 x1.09, 512->128 x1.11, 512->2048 @32x32 x1.07;
     # behind on 128->512 x0.92 and 64->256 x0.87), but routing the narrow / small ones to it (Cout 128, 8192-pixel maps)
@@ -277,7 +366,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     # pixels" (three alternating runs each, same box)
     if (winograd is None and _WINO["pw"] and KH == 1 and KW == 1 and (_WINO["pw"] == "all" or (Cin >= 256 and Cout >= 256 and N * Ho * Wo >= 16384))
             and lib().glass_pointwise_supported(ctypes.byref(d))):
-        return launch("glass_conv1x1_pointwise_nhwc", "pointwise", x, _winograd_weights(w, "pw"))
+        return launch("glass_conv1x1_pointwise_nhwc", "pointwise", x, _packed(w, wt, "pw"))
     use_wino = _WINO["enabled"] if winograd is None else winograd
     if winograd is None and use_wino and KH == 3:
         # the Winograd kernel runs one 64-tile x 64-channel workgroup per CU: below ~96 workgroups (FPN p6, batch-2 res5)
@@ -285,37 +374,43 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
     f43 = winograd == "f43" or (winograd is None and _WINO["f43"] and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin))
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
-        return launch("glass_conv3x3_winograd43_nhwc", "winograd43", x, _winograd_weights(w, True))
+        return launch("glass_conv3x3_winograd43_nhwc", "winograd43", x, _packed(w, wt, True))
     if winograd == "f43":
         raise GlassLibraryError("winograd='f43' but glass_winograd43_supported() rejects this layer")
     if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
         return launch("glass_conv3x3_winograd_nhwc",
-                      "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd", x, _winograd_weights(w))
+                      "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd", x, _packed(w, wt, False))
     if winograd:
         raise GlassLibraryError("winograd=True but glass_winograd_supported() rejects this layer")
-    return launch("glass_conv2d_nhwc", "direct", x, w)
+    return launch("glass_conv2d_nhwc", "direct", x, wt)
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: int = 0,
+def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, relu: int = 0,
            out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """x [M,K] @ w[Nout,K]^T + bias on the same MFMA kernel (H = W = KH = KW = 1)."""
     M, K = x.shape
-    y = conv2d_nhwc(x.view(M, 1, 1, K), w.view(w.shape[0], 1, 1, K), bias, relu=relu,
+    y = conv2d_nhwc(x.view(M, 1, 1, K), w if isinstance(w, ConvWeight) else w.view(w.shape[0], 1, 1, K), bias, relu=relu,
                     out=None if out is None else out.view(M, 1, 1, -1), out_dtype=out_dtype)
     return y.view(M, -1)
 
 
-def local_stem_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
+def _raw(w) -> torch.Tensor:
+    return w.raw if isinstance(w, ConvWeight) else w
+
+
+def local_stem_supported(x: torch.Tensor, w1, w2) -> bool:
     """the fused conv0_1 + conv0_2 + maxpool kernel takes fp32 NHWC4 crops with H, W multiples of 32 (precision fp32, or
     fp16s: the fp16-storage arithmetic, fp16 output)"""
+    w1, w2 = _raw(w1), _raw(w2)
     return (_WINO["precision"] in ("fp32", "fp16s") and os.environ.get("GLASS_LOCAL_STEM", "1") != "0" and x.dtype == torch.float32 and
             x.dim() == 4 and x.shape[-1] == 4 and tuple(w1.shape) == (16, 3, 3, 4) and tuple(w2.shape) == (32, 3, 3, 16) and
             bool(lib().glass_local_stem_supported(int(x.shape[1]), int(x.shape[2]))))
 
 
-def local_stem_fused(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+def local_stem_fused(x: torch.Tensor, w1, b1: torch.Tensor, w2, b2: torch.Tensor) -> torch.Tensor:
     """x [R,H,W,4] -> maxpool2x2(relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2)) [R,H/2,W/2,32] in one kernel; in 'fp16s'
     mode with the fp16 roundings of the unfused fp16-storage chain and an fp16 output."""
+    w1, w2 = _raw(w1), _raw(w2)
     for t, n in ((x, "x"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
         _f32c(t, n)
     R, H, W, _ = x.shape

@@ -1,5 +1,5 @@
 """Root-cause aid for VERDICT r2 #1: an fp16-mode step pipelined beside fp32-mode steps was not bit-identical to its
-synchronous run on the driver box (tests/test_gpu_pipeline.py::test_conv_precision_does_not_leak_between_in_flight_steps).
+synchronous run on the driver box (tests/test_gpu_z_pipeline.py::test_conv_precision_does_not_leak_between_in_flight_steps).
 
   python scripts/diag_fp16_pipeline.py --trials 50                 failure rate of the test's own schedule
   python scripts/diag_fp16_pipeline.py --trials 50 --hook          every ops.native call's outputs are cloned in stream

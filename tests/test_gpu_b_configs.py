@@ -1,8 +1,11 @@
 """GPU: the BASELINE.json configurations as parity / stress cases.
 configs[0] 512x512, pretrain-style cfg (stock GeneralizedRCNN) vs the CPU oracle end to end;
 configs[1] backbone+FPN at 1000x1000 (padded 1024^2) vs the CPU oracle (full size, B=1);
-configs[4] TextOCR-style stress shape (1333 long side, 100 RoIs/img, B=8, orientation head off), fp32:
-           runs, finite, well-formed (the fp16 storage variant of that config is not built)."""
+configs[4] TextOCR-style stress shape (1333 long side, 100 RoIs/img, orientation head off): fp32 B=8 stress (runs, finite,
+           well-formed, parity on one image) and the config's own precision - fp16 storage ('fp16s') and fp16 operands
+           ('fp16') - against the oracle EMULATING that arithmetic (oracle/glass_cpu.py: emulate()).
+(Collection order of the -m gpu suite is parity first: a_stages, b_configs, c_mask_branch, d_known_answers, e_host_tail, then
+the kernel sweeps f_ops, then y_properties / z_pipeline / z_stress - a late flake must not hide the reference-golden tests.)"""
 import os
 
 import numpy as np
@@ -153,7 +156,7 @@ def test_config2_bench_workload_one_image_vs_oracle(sd):
 def test_config4_fp16_conv_mode_tracks_the_fp32_path(sd):
     """BASELINE configs[4] asks for an fp16 run: MODEL.CONV_PRECISION fp16 routes every conv / linear through
     glass_conv2d_nhwc_f16 (operands rounded to fp16, fp16 MFMA, fp32 accumulate and storage).  The op itself is exact
-    against conv(fp16(x), fp16(w)) (tests/test_gpu_ops.py); here the whole model in that mode stays close to the fp32
+    against conv(fp16(x), fp16(w)) (tests/test_gpu_f_ops.py); here the whole model in that mode stays close to the fp32
     path on the TextOCR-style cfg: same recognised characters for > 90 % of the steps, mean probability delta < 5e-3."""
     import glass_amd
     from glass_amd.ops import native as K
