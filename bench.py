@@ -39,6 +39,7 @@ BATCH = 8
 SIDE = 1000
 ROIS = 32
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+DISTINCT_STEPS = 3                  # input sets cycled through the steps (images and boxes differ)
 FP16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (only used by --precision fp16)
 
 
@@ -238,12 +239,18 @@ def main():
 
     B = args.batch
     gidx = [rank * B + i for i in range(B)]                      # global image indices of this rank's shard
-    images = [make_image(g, args.side, args.side).permute(2, 0, 1).float().contiguous().to(dev) for g in gidx]
-    boxes = [make_boxes(g, args.rois, args.side, args.side).to(dev) for g in gidx]
-    inputs = [{"image": im} for im in images]
+    # NSETS distinct input sets (images AND word boxes), cycled step by step: a step that kept state from its predecessor, or
+    # that only ran fast on cache-warm inputs, would show.  Set s of global image g uses seed g + 1000 s.
+    NSETS = DISTINCT_STEPS
+    image_sets = [[make_image(g + 1000 * s, args.side, args.side).permute(2, 0, 1).float().contiguous().to(dev) for g in gidx]
+                  for s in range(NSETS)]
+    box_sets = [[make_boxes(g + 1000 * s, args.rois, args.side, args.side).to(dev) for g in gidx] for s in range(NSETS)]
+    input_sets = [[{"image": im} for im in images] for images in image_sets]
+    images, inputs = image_sets[0], input_sets[0]
     # GlassRunner's front-end (reference glass_runner.py:123-148): uint8 HWC image on the host -> device -> float CHW.
     # The synthetic float images above hold integer values 0..255, so the uint8 route gives bit-identical inputs.
-    host_u8 = [im.permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).cpu().contiguous().pin_memory() for im in images]
+    host_u8_sets = [[im.permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).cpu().contiguous().pin_memory() for im in ims]
+                    for ims in image_sets]
     max_det = cfg.TEST.DETECTIONS_PER_IMAGE
     post = build_post_processor(cfg)                              # PostProcessorAcademic (device kernel)
     out_sizes = [(args.side, args.side)] * B
@@ -252,15 +259,16 @@ def main():
     if args.workload == "backbone":
         il = model.preprocess_image(inputs)
 
-    def local_step_g(from_host=False):
-        """one step as a generator (glass_amd/utils/pipeline.py): yields where the host reads counts back"""
+    def local_step_g(from_host=False, s=0, keep=None):
+        """one step (input set `s`) as a generator (glass_amd/utils/pipeline.py): yields where the host reads counts back"""
+        host_u8, boxes = host_u8_sets[s], box_sets[s]
         if from_host:
             # H2D of the uint8 HWC images (3 MB each, pinned -> stream-ordered) + fused convert (+ resize when the
             # runner's policy asks for one; 1000 x 1000 is inside [MIN_SIZE_TEST, MAX_SIZE_TEST]... the metric's config
             # keeps the image size) on the step's stream
             step_inputs = [{"image": K.image_u8hwc_to_chw(h.to(dev, non_blocking=True), (args.side, args.side))} for h in host_u8]
         else:
-            step_inputs = inputs
+            step_inputs = input_sets[s]
         if args.workload == "backbone":                           # BASELINE configs[1]: trunk + FPN only
             prev = K.set_conv_precision(args.precision)           # (inference_g scopes this itself; no yield in between here)
             try:
@@ -274,21 +282,24 @@ def main():
         # word post-processing (merge, thresholds, polygons, text decode + text-score filter) for the 8 images
         words = yield from post.process_padded_g(det.boxes, det.scores, det.counts_dev, det.text, None, out_sizes,
                                                  {"orientations": det.orient})
+        if keep is not None:                                      # the un-timed self-check: the step's character probabilities
+            keep.append(det.text.clone())
         return pack_words(words.words, max_det, steps_txt)        # fixed-size per-image word records
 
-    def step_g(from_host=False):
-        rec = yield from local_step_g(from_host)
+    def step_g(from_host=False, s=0, keep=None):
+        rec = yield from local_step_g(from_host, s, keep)
         if dist is not None and backend != "nccl":
-            return all_gather_records(rec.cpu())
-        return all_gather_records(rec)
+            return all_gather_records(rec.cpu(), rows=B)
+        return all_gather_records(rec, rows=B)                    # every rank holds B images: no count exchange needed
 
-    def local_step():
-        return drive(local_step_g())
+    def local_step(s=0):
+        return drive(local_step_g(s=s))
 
-    def run_steps(n, from_host=args.from_host, depth=None):
-        """n steps, `--pipeline` of them in flight (each on its own stream; host segments interleaved in a fixed
-        order, so every rank issues its all_gathers in the same order)"""
-        return run_pipelined([lambda: step_g(from_host)] * n, depth=depth or args.pipeline, device=dev)
+    def run_steps(n, from_host=args.from_host, depth=None, first=0):
+        """n steps over the input sets in turn, `--pipeline` of them in flight (each on its own stream; host segments
+        interleaved in a fixed order, so every rank issues its all_gathers in the same order)"""
+        return run_pipelined([(lambda s=(first + i) % NSETS: step_g(from_host, s)) for i in range(n)],
+                             depth=depth or args.pipeline, device=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -296,9 +307,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # lazy initialisation, not part of W or K: the first step on each pipeline stream packs the Winograd weights and
-    # fills that stream's allocator pool (hipMalloc); one step per stream so that a small --warmup cannot leave a cold one
+    # not part of W or K: the first step on each pipeline stream fills that stream's allocator pool (hipMalloc); one step
+    # per stream so that a small --warmup cannot leave a cold one.  (Weights were packed in load_state_dict.)
     run_steps(args.pipeline)
+    # once per run, outside the timed region: every input set's PIPELINED step returns bit for bit the record of its
+    # synchronous run (per-step state / stream hazards would show here; tests/test_gpu_z_pipeline.py holds it for small shapes)
+    pipelined_equals_sync = None
+    if args.workload == "e2e":
+        sync_txt = [[] for _ in range(NSETS)]
+        sync_recs = [drive(step_g(args.from_host, s, sync_txt[s])) for s in range(NSETS)]
+        pipe_txt = [[] for _ in range(2 * NSETS)]
+        piped = run_pipelined([(lambda i=i: step_g(args.from_host, i % NSETS, pipe_txt[i])) for i in range(2 * NSETS)],
+                              depth=args.pipeline, device=dev)
+        torch.cuda.synchronize()
+        # (with random weights the word records are mostly empty - every word fails the text-score threshold - so the
+        #  check that has teeth is the one on the [R, 26, 97] character probabilities)
+        pipelined_equals_sync = all(torch.equal(piped[i], sync_recs[i % NSETS]) and torch.equal(pipe_txt[i][0], sync_txt[i % NSETS][0])
+                                    for i in range(2 * NSETS))
+        if NSETS > 1:
+            assert not torch.equal(sync_txt[0][0], sync_txt[1][0]), "the input sets must differ"
+        assert pipelined_equals_sync, "a pipelined step's output differs from its synchronous run"
+        del sync_txt, pipe_txt, piped
     run_steps(args.warmup)
     if args.gc_freeze:
         # serving-loop hygiene, not skipped work: a generation-2 collection walks every object torch created at
@@ -314,16 +343,36 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    timed_results = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if prof is not None:
         import pstats
         prof.disable()
         pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(35)
+    comm = {"world_size": 1, "backend": None}
+    # the last timed step's gathered records: [world, B, record] on every rank, one count-prefixed record per image
+    last = timed_results[-1]
+    if args.workload == "e2e":
+        assert last.dim() == 3 and last.shape[0] * last.shape[1] == world * B, (tuple(last.shape), world, B)
+        assert bool((last[..., 0] >= 0).all()) and bool((last[..., 0] <= max_det).all()), "a gathered record carries a bad word count"
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        per_rank = torch.empty((world,), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rccl = None
+        if backend == "nccl":
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:                                  # noqa: BLE001 - a report field, never fatal
+                rccl = f"unavailable ({type(e).__name__})"
+        comm = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
+                "per_rank_ms_per_step": [round(v / args.steps * 1e3, 3) for v in per_rank.tolist()],
+                "gathered_records_shape": list(last.shape), "gathered_records_expected": world * B,
+                "devices_visible": ndev, "rank_device": [r % ndev for r in range(world)]}
+        assert comm["world_size"] == world
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
@@ -438,7 +487,9 @@ def main():
                        "images_per_gpu_per_step": B, "rois_per_image": args.rois, "proposals_per_image": 100,
                        "weights": "random-init (seed 1234), reference architecture",
                        "parallelism": f"image-shard x{world}, 1 all_gather of result records/step",
-                       "steps_in_flight": args.pipeline},
+                       "steps_in_flight": args.pipeline, "distinct_steps": NSETS,
+                       "pipelined_step_equals_synchronous_step": pipelined_equals_sync},
+            "comm": comm,
             "images_per_sec_per_gpu": value / world,
             "hbm_peak_reserved_gb": torch.cuda.max_memory_reserved(dev) / 1e9,   # rank 0, whole run (of 288 GB)
             "roofline": {"bound": "mfma", "kernel": ent["kernel"],

@@ -168,8 +168,9 @@ def gathered_to_global(allrec: torch.Tensor, num_items: int) -> torch.Tensor:
 def all_gather_records(local: torch.Tensor, group=None, rows: int = None) -> torch.Tensor:
     """[n_local, record] on every rank -> [world, rows, record]; one collective.  `all_gather_into_tensor` needs the
     same row count on every rank: with `rows` (= `shard_rows(N, W)`) a short shard is padded with all-zero records
-    (count 0); without it every rank must pass the same n_local (N % W == 0) - anything else raises here instead of
-    hanging or mis-viewing inside the collective."""
+    (count 0) and an oversized one raises.  Without `rows` every rank must pass the same n_local (N % W == 0): the ranks
+    first exchange their row counts (one more tiny collective and a host read-back - pass `rows` on a hot path) and ALL of
+    them raise if the counts differ, instead of hanging or mis-viewing inside the payload collective."""
     import torch.distributed as dist
     if rows is not None:
         if local.shape[0] > rows:
@@ -180,6 +181,13 @@ def all_gather_records(local: torch.Tensor, group=None, rows: int = None) -> tor
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local.unsqueeze(0)
     world = dist.get_world_size(group)
+    if rows is None:
+        mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        counts = torch.empty((world,), dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(counts, mine, group=group)
+        counts = counts.tolist()
+        if len(set(counts)) != 1:
+            raise ValueError(f"all_gather_records: ranks hold different record counts {counts}; pass rows=shard_rows(N, W)")
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)      # rank-major concatenation
     return out.view((world,) + tuple(local.shape))

@@ -64,17 +64,32 @@ def segment_scoped(gen: Generator, enter: Callable, leave: Callable):
     """Run `gen` with `tok = enter()` ... `leave(tok)` around EVERY segment (the code between two yields) instead of
     around the whole generator: process-global settings (conv precision) must not stay switched while the other
     in-flight steps of `run_pipelined` execute their segments."""
-    val, first = None, True
+    val, exc, first = None, None, True
     while True:
         tok = enter()
         try:
-            req = next(gen) if first else gen.send(val)
+            if exc is not None:
+                req = gen.throw(exc)                 # an exception thrown in at our yield belongs to the step body
+            else:
+                req = next(gen) if first else gen.send(val)
         except StopIteration as e:
             return e.value
         finally:
             leave(tok)
-        first = False
-        val = yield req
+        first, exc = False, None
+        try:
+            val = yield req
+        except GeneratorExit:
+            # closed at a yield (a failing step of run_pipelined, a caller that gives up): run the body's `finally`
+            # blocks now, inside the scope, not whenever the garbage collector finds the generator
+            tok = enter()
+            try:
+                gen.close()
+            finally:
+                leave(tok)
+            raise
+        except BaseException as e:                   # noqa: BLE001 - forwarded, not handled
+            exc = e
 
 
 def _record_stream(obj, stream, depth: int = 0) -> None:
