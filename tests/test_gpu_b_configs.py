@@ -189,14 +189,15 @@ def _compare_reduced(det, n, ref, what):
     c = int(pc[n])
     fr, fg, ds, db = match_box_sets(pb[n, :c].cpu().numpy(), pl[n, :c].cpu().numpy(), ref["proposals"][0].numpy(), ref["proposals"][1].numpy())
     print(f"[parity] {what}: proposals {c} vs oracle {len(ref['proposals'][0])}: matched {fr:.3f} / {fg:.3f}, max |dlogit| {ds:.3e}, max |dbox| {db:.3e}")
-    assert fr >= 0.9 and fg >= 0.9 and ds < 0.1 and db < 1.0
+    assert fr >= 0.98 and fg >= 0.98 and ds < 0.06 and db < 1.0       # measured: >= 0.99 matched, dlogit <= 4.1e-2, dbox <= 0.51 px
     d = det.detected if det.detected is not None else det
     k = d.counts_host[n]
     fr, fg, ds, db = match_box_sets(d.boxes[n, :k].cpu().numpy(), d.scores[n, :k].cpu().numpy(), ref["pred_boxes"].numpy(), ref["scores"].numpy())
     print(f"[parity] {what}: detections {k} vs oracle {len(ref['scores'])}: matched {fr:.3f} / {fg:.3f}, max |dscore| {ds:.3e}, max |dbox| {db:.3e}")
     # (a detection is scored on ITS proposal, which moved by up to db pixels: the score bound is the proposal logits' bound;
     # observed over the conv kernels this mode has had, i.e. over fp32 summation orders: 5e-3 ... 7e-2)
-    assert fr >= 0.85 and fg >= 0.85 and ds < 0.1 and db < 3.0        # px / degrees on boxes of up to ~1000 px
+    # measured: all but at most ONE detection of 8-22 matched (17 / 18 = 0.944 is the worst case), dscore <= 6.8e-2, dbox <= 0.89 px
+    assert fr >= 0.94 and fg >= 0.94 and ds < 0.09 and db < 1.5       # px / degrees on boxes of up to ~1000 px
 
 
 @pytest.mark.parametrize("prec", ["fp16", "fp16s"])
@@ -222,7 +223,9 @@ def test_fp16_modes_match_their_emulating_oracle_small(sd, prec):
         _compare_reduced(det, n, r, f"{prec} image {n}")
         # greedy decoding under fp16 noise: steps whose top-2 gap is below 1e-2 may legitimately pick the other character
         # (random weights give flat distributions: most RoIs hit such a step somewhere), RoIs are compared up to it
-        assert_text_prob_close(res[n].pred_text_prob.cpu().numpy(), r["pred_text_prob"].numpy(), tol=1e-2, tie_eps=1e-2,
+        # (measured 8e-4 ... 2.0e-3; `max_tied=1.0`: with random weights the distributions are flat and most RoIs meet a
+        #  near-tie at some step - the teacher-forced stage test above is the one with the tight bounds)
+        assert_text_prob_close(res[n].pred_text_prob.cpu().numpy(), r["pred_text_prob"].numpy(), tol=4e-3, tie_eps=1e-2,
                                what=f"{prec} image {n} text (6 injected boxes)", max_tied=1.0)
 
 
@@ -245,9 +248,92 @@ def test_config4_fp16_storage_full_shape_vs_emulating_oracle(sd):
     det = res.batch
     p, q = det.text.cpu().numpy(), ref["pred_text_prob"].numpy()
     assert p.shape == q.shape == (R, 26, 97)
-    assert_text_prob_close(p, q, tol=1e-2, tie_eps=1e-2, what="configs[4] fp16 storage, 1000x1333, 100 RoIs, text", max_tied=1.0)
+    assert_text_prob_close(p, q, tol=8e-3, tie_eps=1e-2, what="configs[4] fp16 storage, 1000x1333, 100 RoIs, text", max_tied=1.0)   # measured 5.5e-3
     # context: the same outputs against the FP32 oracle (what round 1 could only compare with) are further away
     ref32 = O.glass_inference(sd2, [img], cfg, injected_boxes=boxes)[0]["pred_text_prob"].numpy()
     live = (q.sum(-1) > 0) & (ref32.sum(-1) > 0)
     print(f"[parity] configs[4] fp16 storage: mean |dp| vs emulating oracle {np.abs(p - q)[live].mean():.3e}, vs fp32 oracle {np.abs(p - ref32)[live].mean():.3e}")
     _compare_reduced(det, 0, ref, "configs[4] fp16 storage 1000x1333")
+
+
+def _fp16_ulps(got, ref):
+    """|got - ref| in units of the fp16 ulp at |ref| (2^-10 relative; 2^-24 absolute below the smallest normal)"""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    e = np.floor(np.log2(np.maximum(np.abs(ref), 2.0 ** -14)))
+    return np.abs(got - ref) / 2.0 ** (e - 10)
+
+
+def _hist(u):
+    return {f"<={k}": round(float((u <= k).mean()), 5) for k in (0, 1, 2, 4, 8, 32)} | {"max": round(float(u.max()), 1)}
+
+
+def test_fp16s_stages_teacher_forced_ulp_histograms(sd):
+    """why the END-TO-END fp16s bounds are 1e-2-class while every kernel is exact to summation order.
+    Stage by stage, the product in fp16-storage mode against the oracle emulating that arithmetic, errors in fp16 ulps:
+      * one conv fed identical inputs: the two sides differ by fp32 summation order only -> the stored fp16 value is
+        identical for 99.9 % of the elements and one ulp off for the rest (fp32 sums that sit on a rounding boundary; a few
+        cancelling sums are off by more ulps of their own tiny value);
+      * the backbone + FPN (53 + 8 layers, each re-rounding to fp16): flips compound - median 1-2 ulps of the value, about
+        one and a half fp16 epsilons (1.6e-3) of the range at worst, level by level;
+      * the recognition branch fed the ORACLE's pyramid (teacher-forced): crops exact, local / global / fused features
+        within 1e-3 of the range, character probabilities within 2e-3.
+    The 1e-2 / set-matching bounds of the end-to-end fp16s tests are what the chained discontinuities (top-k, NMS, greedy
+    arg-max) make of ulp-level differences, not kernel error; the teacher-forced bounds asserted here are the tight ones."""
+    import glass_amd
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import make_boxes, make_image
+    from oracle import glass_cpu as O
+    dev = torch.device("cuda:0")
+    cfg = _cfg(["MODEL.CONV_PRECISION", "fp16s"])
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd)
+    sizes = [(192, 256), (160, 224)]
+    imgs = [make_image(80 + i, h, w).permute(2, 0, 1).float() for i, (h, w) in enumerate(sizes)]
+    boxes = [make_boxes(80 + i, 5, h, w) * torch.tensor([1, 1, 0.4, 0.5, 1.0]) for i, (h, w) in enumerate(sizes)]
+    with O.emulate("fp16s"):
+        x, _ = O.preprocess(imgs, cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD, 32)
+        feats_ref = O.resnet50_fpn(sd, x)
+        probs_ref, inter = O.recognizer_branch(sd, x, feats_ref, boxes, cfg, return_intermediates=True)
+    prev = K.set_conv_precision("fp16s")
+    try:
+        # (1) one layer, identical inputs: the stem
+        nhwc4 = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 1)).contiguous().to(dev)
+        w = m.backbone.w["stem"]
+        y = K.conv2d_nhwc(nhwc4, *w, stride=2, padding=3, relu=1, out_dtype=torch.float16)
+        with O.emulate("fp16s"):
+            y_ref = O._st(O._cbn(x, sd, "backbone.bottom_up.stem.conv1", stride=2, padding=3, relu=True))
+        yn = y.float().permute(0, 3, 1, 2).cpu().numpy()
+        u = _fp16_ulps(yn, y_ref.numpy())
+        d = float(np.abs(yn - y_ref.numpy()).max() / float(y_ref.abs().max()))
+        print(f"[fp16s ulps] stem conv, identical input: {_hist(u)}, max |d| / range {d:.2e}")
+        # (more than one ulp only where the sum cancels: |result| << |terms|, so an fp32-rounding-sized difference of the
+        #  sum spans several ulps of the tiny result)
+        assert (u <= 1).mean() > 0.9999 and (u > 0).mean() < 0.02 and d < 2.0 ** -10          # one fp16 ulp of the largest value
+        # (2) the whole backbone + FPN
+        feats = m.backbone.forward_nhwc(nhwc4)
+        for k in ("p2", "p3", "p4", "p5"):
+            assert feats[k].dtype == torch.float16
+            u = _fp16_ulps(feats[k].float().permute(0, 3, 1, 2).cpu().numpy(), feats_ref[k].numpy())
+            rng = float(feats_ref[k].abs().max())
+            d = float(np.abs(feats[k].float().permute(0, 3, 1, 2).cpu().numpy() - feats_ref[k].numpy()).max())
+            print(f"[fp16s ulps] backbone + FPN {k}: {_hist(u)}, max |d| / range {d / rng:.2e}")
+            assert np.median(u) <= 2 and d / rng < 4e-3      # (signed, cancelling FPN sums: ulps of the VALUE overstate; see d / range)
+        # (3) recognition branch on the ORACLE's pyramid (fp16-representable by construction)
+        tf = {k: v.permute(0, 2, 3, 1).contiguous().to(dev).half() for k, v in feats_ref.items()}
+        for k, v in tf.items():
+            assert torch.equal(v.float().cpu(), feats_ref[k].permute(0, 2, 3, 1))      # nothing lost by the cast
+        bcat = torch.cat(boxes).contiguous().to(dev)
+        ri = torch.tensor([0] * 5 + [1] * 5, dtype=torch.int32, device=dev)
+        probs, got = m.roi_heads.recognizer_branch_batched(nhwc4, tf, bcat, ri, 2, return_intermediates=True)
+    finally:
+        K.set_conv_precision(prev)
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(float(np.abs(np.asarray(b)).max()), 1e-30))
+    xcat = got["xcat"].permute(0, 3, 1, 2).cpu().numpy()
+    r = {"crops": rel(got["crops"][..., :3].permute(0, 3, 1, 2).cpu().numpy(), inter["crops"].numpy()),
+         "local": rel(xcat[:, 0::2], inter["local"].numpy()), "global": rel(xcat[:, 1::2], inter["global"].numpy()),
+         "fused": rel(got["fused"].permute(0, 3, 1, 2).cpu().numpy(), inter["fused"].numpy())}
+    dp = float(np.abs(probs.cpu().numpy() - probs_ref.numpy()).max())
+    print(f"[fp16s teacher-forced] recognition branch, max |d| / range: {r}, character probabilities max |dp| {dp:.2e}")
+    # measured (round 3): crops 5.9e-6, global 5.0e-4, local 1.2e-3, fused 8.3e-5 of the range; probabilities 2.6e-4
+    assert r["crops"] < 1e-5 and r["global"] < 1e-3 and r["local"] < 2.5e-3 and r["fused"] < 5e-4
+    assert_text_prob_close(probs.cpu().numpy(), probs_ref.numpy(), tol=1e-3, tie_eps=1e-3, what="fp16s teacher-forced text", max_tied=1.0)

@@ -130,6 +130,39 @@ def test_mask_head_matches_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp16", "fp16s"])
+def test_mask_head_in_the_fp16_modes_matches_the_emulating_oracle(prec):
+    """with MASK_ON the fp16 modes round the operands of the deconv and of the predictor as well; the oracle's
+    emulation restates that, so the mask probabilities agree to fp32 summation order (x fp16 re-rounding of one ulp)."""
+    import glass_amd  # noqa: F401
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.modeling.roi_heads.rotated_mask_head import RotatedMaskRCNNConvUpsampleHead
+    from glass_amd.ops import native as K
+    from glass_amd.structures.core import ShapeSpec
+    from glass_amd.utils.synth import make_state_dict
+    from oracle import glass_cpu as O
+    cfg = get_glass_cfg(os.path.join(ROOT, "configs", "glass_icdar15_mi355x.yaml"))
+    sd = make_state_dict(1234, parts=("mask",))
+    head = RotatedMaskRCNNConvUpsampleHead(cfg, ShapeSpec(channels=256, height=14, width=14))
+    with K.packing_for(prec):
+        head.import_weights(sd, _dev(), "roi_heads.mask_head.")
+    torch.cuda.synchronize()
+    x = torch.randn((5, 256, 14, 14), generator=torch.Generator().manual_seed(4))
+    with O.emulate(prec):
+        ref = torch.sigmoid(O.mask_head_logits(sd, x))
+    ref32 = torch.sigmoid(O.mask_head_logits(sd, x))
+    prev = K.set_conv_precision(prec)
+    try:
+        got = head.forward_nhwc(x.permute(0, 2, 3, 1).contiguous().to(_dev())).cpu()
+        assert K.last_conv_path() in ("direct_fp16", "packed_fp16")
+    finally:
+        K.set_conv_precision(prev)
+    d_emu, d_32 = float((got - ref).abs().max()), float((got - ref32).abs().max())
+    print(f"[parity] mask head {prec}: max |dp| vs emulating oracle {d_emu:.2e}, vs fp32 oracle {d_32:.2e}")
+    assert d_emu < 2e-4 and d_emu < d_32
+
+
+@pytest.mark.gpu
 def test_end_to_end_with_mask_inference_matches_oracle():
     """eval-CLI setting MODEL.ROI_MASK_HEAD.MASK_INFERENCE True (reference tools/eval_glass.py:106): pred_masks and
     pred_rboxes appear, raw 28x28 masks match the oracle, pasted masks match after the meta-arch postprocess."""
