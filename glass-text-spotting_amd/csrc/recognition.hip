@@ -328,9 +328,11 @@ struct DecParams {
   float* out;
   int* pred;
   float* h0; float* h1; float* inp; int* yprev;     // workspace: state (double-buffered), [emb|ctx], last argmax
+  float* logits;                                    // glass_attention_decode_step only: raw fc outputs [R, C] (else null)
 };
 
-// step < 0: only the attention part (initial state h = 0, y = 0); do_att == 0: only the fc part (last step)
+// step == -1: only the attention part with the initial input (y = 0); step == -2: only the attention part with y read from
+// p.yprev (one decoder step of a caller-driven search, glass_attention_decode_step); do_att == 0: only the fc part (last step)
 // DEC_RB = RoIs per workgroup: 4 when there are enough RoIs to fill the chip with 4-RoI workgroups, else 2 or 1
 // (R = 256: 64 workgroups of 4 leave 3/4 of the CUs idle for 38 us per step; 256 workgroups of 1 take 12 us).
 template <int DEC_RB>
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void dec_fc_att_kernel(DecParams p, const floa
   const int T = p.T, C = p.C;
 #pragma unroll
   for (int r = 0; r < DEC_RB; ++r) h[r][u] = (r < nr) ? hcur[(long)(r0 + r) * DEC_D + u] : 0.f;
-  if (u < DEC_RB) ycur[u] = (step < 0 || u >= nr) ? 0 : p.yprev[r0 + u];
+  if (u < DEC_RB) ycur[u] = (step == -1 || u >= nr) ? 0 : p.yprev[r0 + u];
   __syncthreads();
   if (step >= 0) {
     // ---- logits = fc(h) * temperature; softmax over C; argmax (first maximum)
@@ -356,7 +358,10 @@ __global__ __launch_bounds__(256) void dec_fc_att_kernel(DecParams p, const floa
       for (int r = 0; r < DEC_RB; ++r) acc[0][r] = p.fcB[u];
       stream_matvec<1, DEC_RB, 16>(reinterpret_cast<const float4*>(p.fcW), C, 0, u, DEC_D / 4, &h[0][0], DEC_D, acc);
 #pragma unroll
-      for (int r = 0; r < DEC_RB; ++r) logit[r][u] = acc[0][r] * p.temperature;
+      for (int r = 0; r < DEC_RB; ++r) {
+        logit[r][u] = acc[0][r] * p.temperature;
+        if (p.logits != nullptr && r < nr) p.logits[(long)(r0 + r) * C + u] = logit[r][u];
+      }
     }
     __syncthreads();
     if (wave < nr) {
@@ -565,7 +570,7 @@ extern "C" int glass_attention_decode(const float* x, const float* xproj, const 
   DecParams p;
   p.x = x; p.xproj = xproj; p.sW = w->sW; p.sB = w->sB; p.wW = w->wW; p.wB = w->wB; p.emb = w->emb; p.w_ih = w->w_ih;
   p.w_hh = w->w_hh; p.b_ih = w->b_ih; p.b_hh = w->b_hh; p.fcW = w->fcW; p.fcB = w->fcB; p.temperature = w->temperature;
-  p.R = R; p.T = T; p.C = C; p.max_len = max_len; p.out = out; p.pred = pred_scratch;
+  p.R = R; p.T = T; p.C = C; p.max_len = max_len; p.out = out; p.pred = pred_scratch; p.logits = nullptr;
   float* ws = static_cast<float*>(workspace);
   p.h0 = ws; p.h1 = ws + (size_t)R * D; p.inp = ws + (size_t)R * D * 2;
   p.yprev = reinterpret_cast<int*>(ws + (size_t)R * D * 4);
@@ -588,5 +593,46 @@ extern "C" int glass_attention_decode(const float* x, const float* xproj, const 
   hipLaunchKernelGGL(decode_break_mask_kernel, dim3(num_images), dim3(256), 0, s, pred_scratch, roi_image, R, max_len, C, eos,
                      out);
   GLASS_CHECK_LAUNCH("glass_attention_decode(mask)");
+  return GLASS_OK;
+}
+
+// One decoder step for a caller-driven search (AttentionRecognitionHead.beam_search, reference prediction_aster.py:133-134:
+// `output, state, alpha = self.decoder(x, state, y_prev)`): attention with h_in and the embedding of y_prev, GRU cell, fc.
+extern "C" int64_t glass_decode_step_workspace_bytes(int R, int D) {
+  return (int64_t)((size_t)R * 2 * D) * sizeof(float) + (int64_t)R * 2 * sizeof(int);
+}
+
+extern "C" int glass_attention_decode_step(const float* x, const float* xproj, const glass_decoder_weights* w, int R, int T, int D,
+                                           int C, const float* h_in, const int* y_prev, float* h_out, float* logits_out,
+                                           float* probs_out, void* workspace, int64_t workspace_bytes, glass_stream_t stream) {
+  GLASS_CHECK_ARG(D == DEC_D && T > 0 && T <= DEC_TMAX && C > 0 && C <= DEC_CMAX,
+                  "glass_attention_decode_step: needs D=256, T<=64, C<=256 (got D=%d T=%d C=%d)", D, T, C);
+  if (R == 0) return GLASS_OK;
+  GLASS_CHECK_ARG(x && xproj && w && h_in && y_prev && h_out && logits_out && probs_out && workspace && h_in != h_out,
+                  "glass_attention_decode_step: null pointer (or h_out aliases h_in)");
+  GLASS_CHECK_ARG(workspace_bytes >= glass_decode_step_workspace_bytes(R, D), "glass_attention_decode_step: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  DecParams p;
+  p.x = x; p.xproj = xproj; p.sW = w->sW; p.sB = w->sB; p.wW = w->wW; p.wB = w->wB; p.emb = w->emb; p.w_ih = w->w_ih;
+  p.w_hh = w->w_hh; p.b_ih = w->b_ih; p.b_hh = w->b_hh; p.fcW = w->fcW; p.fcB = w->fcB; p.temperature = w->temperature;
+  p.R = R; p.T = T; p.C = C; p.max_len = 1; p.out = probs_out; p.logits = nullptr;
+  float* ws = static_cast<float*>(workspace);
+  p.h0 = p.h1 = nullptr; p.inp = ws;
+  int* iscratch = reinterpret_cast<int*>(ws + (size_t)R * 2 * D);
+  p.pred = iscratch;
+  const int rb = R >= 1024 ? 4 : R >= 512 ? 2 : 1;
+  const dim3 ga(cdiv(R, rb)), gg(cdiv(R, GRU_RB), DEC_D / GRU_UB);
+  auto fc_att = [&](const float* hcur, int step, int do_att) {
+    if (rb == 4) hipLaunchKernelGGL(dec_fc_att_kernel<4>, ga, dim3(256), 0, s, p, hcur, step, do_att);
+    else if (rb == 2) hipLaunchKernelGGL(dec_fc_att_kernel<2>, ga, dim3(256), 0, s, p, hcur, step, do_att);
+    else hipLaunchKernelGGL(dec_fc_att_kernel<1>, ga, dim3(256), 0, s, p, hcur, step, do_att);
+  };
+  p.yprev = const_cast<int*>(y_prev);            // read only in the attention-only launch
+  fc_att(h_in, -2, 1);                           // inp = [embedding(y_prev) | attention context of h_in]
+  hipLaunchKernelGGL(dec_gru_kernel, gg, dim3(256), 0, s, p, h_in, h_out);
+  p.yprev = iscratch + R;                        // the fc launch records its arg-max: into the scratch, not into the caller's y
+  p.logits = logits_out;
+  fc_att(h_out, 0, 0);                           // logits = fc(h_out) * temperature, probs = softmax(logits)
+  GLASS_CHECK_LAUNCH("glass_attention_decode_step");
   return GLASS_OK;
 }

@@ -54,11 +54,73 @@ class ASTER_V2(InferenceModule):
             "temperature": float(sd[q + "temperature"].reshape(-1)[0]) if (q + "temperature") in sd else 1.0,
         }
 
-    def beam_search(self, x, beam_width, eos):
-        """reference prediction_aster.py:101-222: never called on the inference path (`forward` -> `sample`, :63-99,
-        greedy) nor by any tool of the reference; not built."""
-        raise NotImplementedError("AttentionRecognitionHead.beam_search (reference prediction_aster.py:101-222) is dead code in the "
-                                  "reference's inference path (greedy `sample` is what runs); this build implements `sample` only")
+    def beam_search(self, x: torch.Tensor, beam_width: int, eos: int = 0):
+        """`AttentionRecognitionHead.beam_search` (reference prediction_aster.py:101-222; never called by the reference's
+        inference path, which samples greedily): x [B,T,D] -> (symbols [B, max_word_len] of the best beam, its score [B]).
+        The per-step arithmetic - attention, GRU cell, fc - is one `glass_attention_decode_step` on the B x beam_width
+        inflated batch; the search itself is the reference's host logic on small device tensors: log-softmax + running
+        scores, top-k over beam x classes, predecessor re-indexing of the state, <eos> beams frozen at -inf, and the
+        back-tracking pass including its "ended sequences replace the worst beams" bookkeeping.  One deliberate difference:
+        `candidates / num_classes` is floor division here, as it was under the torch version the reference was written for -
+        on a current torch the reference line yields a float index and `index_select` raises (oracle/make_golden.py --beam
+        generates the golden from the reference function with exactly that operator restored)."""
+        x = x.contiguous()
+        B, T, D = x.shape
+        k, C, L = int(beam_width), self.num_classes, self.max_word_len
+        dev_ = x.device
+        xproj = K.linear(x.view(B * T, D), self.w["xW"], self.w["xB"]).view(B, T, D)
+        xi = x.unsqueeze(1).expand(B, k, T, D).reshape(B * k, T, D).contiguous()              # ABC -> AABBCC
+        xpi = xproj.unsqueeze(1).expand(B, k, T, D).reshape(B * k, T, D).contiguous()
+        state = torch.zeros((B * k, D), dtype=torch.float32, device=dev_)
+        pos_index = (torch.arange(B, device=dev_) * k).view(-1, 1)
+        sequence_scores = torch.full((B * k, 1), -float("inf"), device=dev_)
+        sequence_scores[torch.arange(B, device=dev_) * k] = 0.0
+        y_prev = torch.zeros((B * k,), dtype=torch.int32, device=dev_)
+        stored_scores, stored_predecessors, stored_emitted_symbols = [], [], []
+        for _ in range(L):
+            logits, _, state = K.attention_decode_step(xi, xpi, self.w, state, y_prev, C)
+            log_softmax_output = torch.log_softmax(logits, dim=1)
+            sequence_scores = sequence_scores.repeat(1, C) + log_softmax_output
+            scores, candidates = sequence_scores.view(B, -1).topk(k, dim=1)
+            y_prev = (candidates % C).view(B * k).to(torch.int32)
+            sequence_scores = scores.view(B * k, 1)
+            predecessors = (candidates // C + pos_index.expand_as(candidates)).view(B * k, 1)
+            state = state.index_select(0, predecessors.squeeze(1)).contiguous()
+            stored_scores.append(sequence_scores.clone())
+            sequence_scores = sequence_scores.masked_fill(y_prev.view(-1, 1) == eos, -float("inf"))
+            stored_predecessors.append(predecessors)
+            stored_emitted_symbols.append(y_prev.long())
+        # ---- back-tracking (host bookkeeping of the reference, :165-222), on CPU copies of the small decision tables
+        sc = [t.cpu() for t in stored_scores]
+        pr = [t.cpu() for t in stored_predecessors]
+        sy = [t.cpu() for t in stored_emitted_symbols]
+        pos = pos_index.cpu()
+        p = []
+        lens = [[L] * k for _ in range(B)]
+        sorted_score, sorted_idx = sc[-1].view(B, k).topk(k)
+        s = sorted_score.clone()
+        batch_eos_found = [0] * B
+        t_pred = (sorted_idx + pos.expand_as(sorted_idx)).view(B * k)
+        for t in range(L - 1, -1, -1):
+            current_symbol = sy[t].index_select(0, t_pred)
+            t_pred = pr[t].index_select(0, t_pred).squeeze(1)
+            eos_indices = sy[t].eq(eos).nonzero()
+            for i in range(eos_indices.size(0) - 1, -1, -1):
+                idx = int(eos_indices[i][0])
+                b_idx = idx // k
+                res_k_idx = k - (batch_eos_found[b_idx] % k) - 1
+                batch_eos_found[b_idx] += 1
+                res_idx = b_idx * k + res_k_idx
+                t_pred[res_idx] = pr[t][idx, 0]
+                current_symbol[res_idx] = sy[t][idx]
+                s[b_idx, res_k_idx] = sc[t][idx, 0]
+                lens[b_idx][res_k_idx] = t + 1
+            p.append(current_symbol)
+        s, re_sorted_idx = s.topk(k)
+        re_sorted_idx = (re_sorted_idx + pos.expand_as(re_sorted_idx)).view(B * k)
+        p = [step.index_select(0, re_sorted_idx).view(B, k, -1) for step in reversed(p)]
+        p = torch.cat(p, -1)[:, 0, :]
+        return p.to(dev_), s[:, 0].to(dev_)
 
     def forward(self, features: torch.Tensor, labels=None, roi_image: Optional[torch.Tensor] = None,
                 num_images: int = 1) -> torch.Tensor:

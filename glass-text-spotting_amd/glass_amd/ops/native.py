@@ -682,6 +682,30 @@ def attention_decode(x: torch.Tensor, xproj: torch.Tensor, weights: dict, roi_im
     return out
 
 
+def attention_decode_step(x: torch.Tensor, xproj: torch.Tensor, weights: dict, h: torch.Tensor, y_prev: torch.Tensor,
+                          num_classes: int):
+    """one decoder step (reference DecoderUnit.forward): x, xproj [R,T,D], state h [R,D], y_prev int32 [R] ->
+    (logits [R,C], probabilities [R,C], next state [R,D])."""
+    _f32c(x, "x"); _f32c(xproj, "xproj"); _f32c(h, "h"); _i32(y_prev, "y_prev")
+    R, T, D = x.shape
+    logits = torch.empty((R, num_classes), dtype=torch.float32, device=x.device)
+    probs = torch.empty((R, num_classes), dtype=torch.float32, device=x.device)
+    h_out = torch.empty((R, D), dtype=torch.float32, device=x.device)
+    if R == 0:
+        return logits, probs, h_out
+    w = DecoderWeights()
+    for n in ("sW", "sB", "wW", "wB", "emb", "w_ih", "w_hh", "b_ih", "b_hh", "fcW", "fcB"):
+        setattr(w, n, _dev(_f32c(weights[n], n)))
+    w.temperature = float(weights["temperature"])
+    nbytes = int(lib().glass_decode_step_workspace_bytes(R, D))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    check(lib().glass_attention_decode_step(c_void_p(_dev(x)), c_void_p(_dev(xproj)), ctypes.byref(w), R, T, D, int(num_classes),
+                                            c_void_p(_dev(h)), c_void_p(_dev(y_prev)), c_void_p(_dev(h_out)), c_void_p(_dev(logits)),
+                                            c_void_p(_dev(probs)), c_void_p(_dev(ws)), ctypes.c_int64(nbytes), c_void_p(stream_handle())),
+          "glass_attention_decode_step")
+    return logits, probs, h_out
+
+
 def detections_finalize(boxes: torch.Tensor, scores: torch.Tensor, orient: Optional[torch.Tensor],
                         text: Optional[torch.Tensor], counts: torch.Tensor, roi_start: Optional[torch.Tensor],
                         scale_xy: torch.Tensor, out_hw: torch.Tensor, min_box_dim: float, do_filter_small: bool):

@@ -366,6 +366,17 @@ int glass_attention_decode(const float* x, const float* xproj, const glass_decod
                            int num_images, int T, int D, int C, int max_len, int eos, float* out, int* pred_scratch,
                            void* workspace, int64_t workspace_bytes, glass_stream_t stream);
 
+/* ONE step of the same decoder for a search driven by the caller - `output, state, alpha = self.decoder(x, state, y_prev)`
+ * inside AttentionRecognitionHead.beam_search (glass/modeling/recognition/prediction_aster.py:133-134, DecoderUnit.forward
+ * :291-302): additive attention with the state h_in [R,D] -> context, embedding of y_prev [R] (ints), GRU cell -> h_out
+ * [R,D] (must not alias h_in), fc(h_out) * temperature -> logits_out [R,C] and their softmax probs_out [R,C].  Same
+ * weights, packing and limits as glass_attention_decode; R here is batch x beam width (rows may repeat the same x /
+ * xproj sequence: pass the inflated tensors).  `workspace`: >= glass_decode_step_workspace_bytes().  Three launches. */
+int64_t glass_decode_step_workspace_bytes(int R, int D);
+int glass_attention_decode_step(const float* x, const float* xproj, const glass_decoder_weights* w, int R, int T, int D, int C,
+                                const float* h_in, const int* y_prev, float* h_out, float* logits_out, float* probs_out,
+                                void* workspace, int64_t workspace_bytes, glass_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,37 @@ def test_decoder_golden_and_early_break(cfg, sd_full, golden_dir):
     assert _maxdiff(y2[4:], ref.numpy()) < 1e-4
 
 
+def test_beam_search_matches_reference_golden(cfg, sd_full, golden_dir):
+    """f4: AttentionRecognitionHead.beam_search (reference prediction_aster.py:101-222) - per-step arithmetic through
+    glass_attention_decode_step, the search / back-tracking on the host as in the reference.  Golden: the reference's own
+    function (tests/golden/beam_search.npz, oracle/make_golden.py --beam): best-beam symbols identical, scores to 1e-4.
+    Width 1 is greedy decoding: its symbols must also equal the arg-max of `sample`'s probabilities."""
+    from glass_amd.modeling.recognition.recognizer_decoder import ASTER_V2
+    from glass_amd.structures.core import ShapeSpec
+    g = _g(golden_dir, "beam_search.npz")
+    pre = "roi_heads.recognizer_head.decoder."
+    sd = dict(sd_full)
+    sd[pre + "recognizer.decoder.fc.weight"] = sd_full[pre + "recognizer.decoder.fc.weight"] * float(g["fc_scale"])
+    sd[pre + "recognizer.decoder.fc.bias"] = sd_full[pre + "recognizer.decoder.fc.bias"].clone()
+    sd[pre + "recognizer.decoder.fc.bias"][0] += float(g["bias0"])
+    dec = ASTER_V2(cfg, ShapeSpec(channels=256))
+    dec.import_weights(sd, _dev(), pre)
+    for name in ("a", "b", "c"):
+        x = torch.from_numpy(g[f"{name}:x"]).to(_dev())
+        width = int(g[f"{name}:width"])
+        p, s = dec.beam_search(x, width, 0)
+        assert p.cpu().numpy().tolist() == g[f"{name}:p"].tolist(), (name, p.cpu().numpy().tolist(), g[f"{name}:p"].tolist())
+        assert _maxdiff(s.cpu().numpy(), g[f"{name}:s"]) < 1e-4, name
+        if width == 1:
+            # greedy `sample` agrees up to and including each row's first <eos> (a finished beam scores -inf afterwards and
+            # emits index 0 for the rest; `sample` keeps decoding)
+            probs, sym = dec(x).cpu().numpy(), p.cpu().numpy()
+            for r in range(sym.shape[0]):
+                n = int(np.argmax(sym[r] == 0)) + 1 if (sym[r] == 0).any() else sym.shape[1]
+                live = probs[r, :n].sum(-1) > 0              # rows after the batch-global break of `sample` stay zero
+                assert (probs[r, :n].argmax(-1)[live] == sym[r, :n][live]).all(), r
+
+
 # ------------------------------------------------------------------ oracle: d2-owned stages
 IMG_SIZES = [(120, 150), (128, 100)]
 

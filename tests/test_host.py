@@ -273,9 +273,7 @@ def test_unbuilt_reference_names_fail_with_a_reason_not_a_keyerror():
     assert "ResNetFeatureExtractorV2" not in dict(iter(LOCAL_FEATURE_EXTRACTOR_REGISTRY))
     with pytest.raises(KeyError):
         LOCAL_FEATURE_EXTRACTOR_REGISTRY.get("NoSuchExtractor")
-    dec = ASTER_V2(_cfg(), ShapeSpec(channels=256))
-    with pytest.raises(NotImplementedError, match="beam_search"):
-        dec.beam_search(None, 5, 1)
+    assert callable(ASTER_V2(_cfg(), ShapeSpec(channels=256)).beam_search)     # built in round 3 (tests/test_gpu_a_stages.py)
     cfg = _cfg(["MODEL.ROI_RECOGNIZER_HEAD.RECOGNIZER_HEAD.POOLER_PAD.NAME", "FeatPadV2"])
     with pytest.raises(NotImplementedError, match="axis-aligned"):
         glass_amd.build_model(cfg)
