@@ -523,6 +523,9 @@ def main():
         }
         line.update(extras)
         line["lib_source_sha16"] = source_sha16()
+        # weights are packed in load_state_dict (ops.native.ConvWeight); a launch that had to pack at launch time would
+        # mean a layer / precision the loader did not foresee - 0 on this workload
+        line["conv_launches_that_packed_weights_at_launch"] = K.packs_on_the_fly()
         if args.from_host:
             line["config"]["inputs"] = "uint8 HWC in pinned host memory (--from-host): PCIe-inclusive, NOT the contract's value"
         if not args.no_cpu_baseline and world == 1:

@@ -4,6 +4,8 @@
 // halves whose bits differ at the end.  Forms:
 //   1  v_pk_fma_f32 (plain)                        2  v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[0,1] (broadcast) + v_pk_fma_f32
 //   3  v_pk_add_f32 neg_lo/neg_hi + v_pk_fma_f32   4  form 1 with a third of the lanes switched off (EXEC)
+//   5  v_pk_fma_f32 op_sel_hi:[0,1,1]   6 / 7  v_pk_mul_f32 with only op_sel / only op_sel_hi   8  v_pk_mov_b32 op_sel
+//   9  SDWA (v_cvt_f32_f16_sdwa src0_sel:WORD_1)   10  DPP (v_mov_b32_dpp quad_perm)
 //   hipcc --offload-arch=gfx950 -O3 -I include -o pk_vs_convh16 scripts/micro/pk_vs_convh16.hip -ldl
 //   ./pk_vs_convh16 glass-text-spotting_amd/libglass_hip.so [rounds] [aggressor: 1 conv 3x3 | 2 none | 3 conv 1x1 | 4 none, 16x victim grid | 5 VALU spinner | 6 + 64 KB LDS | 7 ~240 VGPRs]
 #include <hip/hip_runtime.h>
@@ -56,6 +58,23 @@ __global__ __launch_bounds__(256) void victim_kernel(Report* rep, int iters) {
         float n0, n1;
         asm volatile("v_fma_f32 %0, %3, %4, %6\n\tv_fma_f32 %1, %2, %5, %7" : "=&v"(n0), "=&v"(n1) : "v"(slo), "v"(shi), "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
         slo = n0; shi = n1;
+      } else if constexpr (FORM == 9) {
+        // SDWA sub-dword select (the fp16 kernels' own epilogues use v_cvt_f32_f16_sdwa): convert the HIGH half word
+        const unsigned packed = (__float_as_uint(x[0]) & 0xffff0000u) | 0x3c00u;       // hi = top bits of x.lo as an fp16 pattern
+        float c_sdwa, c_ref;
+        asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(c_sdwa) : "v"(packed));
+        asm volatile("v_lshrrev_b32 %0, 16, %1\n\ts_nop 1\n\tv_cvt_f32_f16 %0, %0" : "=&v"(c_ref) : "v"(packed));
+        c_sdwa = (c_sdwa != c_sdwa || c_sdwa > 1e4f || c_sdwa < -1e4f) ? 0.5f : c_sdwa;
+        c_ref = (c_ref != c_ref || c_ref > 1e4f || c_ref < -1e4f) ? 0.5f : c_ref;
+        x[0] = __builtin_fmaf(x[0], 0.999f, 1e-3f * c_sdwa); x[1] = x[0];
+        slo = __builtin_fmaf(slo, 0.999f, 1e-3f * c_ref); shi = slo;
+      } else if constexpr (FORM == 10) {
+        // DPP (wave reductions): neighbour exchange by quad_perm vs the LDS-crossbar path (ds_bpermute)
+        float nb_dpp;
+        asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(nb_dpp) : "v"(x[0]));
+        const float nb_ref = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 1) * 4, __float_as_uint(slo)));
+        x[0] = __builtin_fmaf(nb_dpp, 0.999f, 0.0123f); x[1] = x[0];
+        slo = __builtin_fmaf(nb_ref, 0.999f, 0.0123f); shi = slo;
       } else if constexpr (FORM == 5) {
         // x = fma(bcast(a.lo), x, b): the compiler's idiom for scalar * vector
         asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[0,1,1]" : "+v"(x) : "v"(a), "v"(b));
@@ -165,6 +184,8 @@ static void launch_victim(int form, Report* rep, int blocks, int iters, hipStrea
     case 6: hipLaunchKernelGGL(victim_kernel<6>, dim3(blocks), dim3(256), 0, s, rep, iters); break;
     case 7: hipLaunchKernelGGL(victim_kernel<7>, dim3(blocks), dim3(256), 0, s, rep, iters); break;
     case 8: hipLaunchKernelGGL(victim_kernel<8>, dim3(blocks), dim3(256), 0, s, rep, iters); break;
+    case 9: hipLaunchKernelGGL(victim_kernel<9>, dim3(blocks), dim3(256), 0, s, rep, iters); break;
+    case 10: hipLaunchKernelGGL(victim_kernel<10>, dim3(blocks), dim3(256), 0, s, rep, iters); break;
     default: hipLaunchKernelGGL(victim_kernel<4>, dim3(blocks), dim3(256), 0, s, rep, iters); break;
   }
 }
@@ -201,8 +222,8 @@ int main(int argc, char** argv) {
   CK(hipStreamSynchronize(sa));
   Report* rep;
   CK(hipMalloc(&rep, sizeof(Report)));
-  const char* fname[] = {"", "v_pk_fma_f32", "v_pk_mul_f32 op_sel bcast + v_pk_fma_f32", "v_pk_add_f32 neg + v_pk_fma_f32", "v_pk_fma_f32, 1/3 of lanes off", "v_pk_fma_f32 op_sel_hi:[0,1,1] (scalar bcast)", "v_pk_mul_f32 op_sel:[0,1] only", "v_pk_mul_f32 op_sel_hi:[0,1] only", "v_pk_mov_b32 op_sel:[1,0]"};
-  for (int form = 1; form <= 8; ++form) {
+  const char* fname[] = {"", "v_pk_fma_f32", "v_pk_mul_f32 op_sel bcast + v_pk_fma_f32", "v_pk_add_f32 neg + v_pk_fma_f32", "v_pk_fma_f32, 1/3 of lanes off", "v_pk_fma_f32 op_sel_hi:[0,1,1] (scalar bcast)", "v_pk_mul_f32 op_sel:[0,1] only", "v_pk_mul_f32 op_sel_hi:[0,1] only", "v_pk_mov_b32 op_sel:[1,0]", "v_cvt_f32_f16_sdwa src0_sel:WORD_1", "v_mov_b32_dpp quad_perm"};
+  for (int form = 1; form <= 10; ++form) {
     CK(hipMemset(rep, 0, sizeof(Report)));
     for (int r = 0; r < rounds; ++r) {
       if ((aggr == 1 || aggr == 3) && conv(&d, x, u, nullptr, nullptr, y, 3, sa) != 0) { fprintf(stderr, "conv: %s\n", err()); return 1; }
