@@ -6,6 +6,8 @@ synchronous run on the driver box (tests/test_gpu_z_pipeline.py::test_conv_preci
                                                                    order; the FIRST diverging launch of a failing step is named
   --order fp16 | fp32 | mixed     which models are interleaved          --prio same   both pipeline streams in the normal class
   --h16 0                         fp16 mode without conv_h16_kernel     --depth N
+Result (profiles/r03_fp16_pipeline_rootcause.log): a packed-f32 / double-rate-MFMA hardware interaction, DESIGN.md section 4.
+(Round 2 also had `--fill`: 600 dummy entries in the then-global packed-weight cache, to rule eviction out; the cache is gone.)
 """
 import argparse
 import os
@@ -24,7 +26,6 @@ ap.add_argument("--h16", type=int, default=1)
 ap.add_argument("--depth", type=int, default=2)
 ap.add_argument("--size", default="128x160")
 ap.add_argument("--rois", type=int, default=4)
-ap.add_argument("--fill", action="store_true", help="fill the packed-weight cache with 600 dummy entries first (a long test session)")
 args = ap.parse_args()
 
 import glass_amd  # noqa: E402
@@ -35,10 +36,6 @@ from glass_amd.utils.synth import make_boxes, make_image, make_state_dict  # noq
 
 dev = torch.device("cuda:0")
 K.set_conv_h16(bool(args.h16))
-if args.fill and hasattr(K, "_winograd_weights"):
-    for i in range(600):
-        w = torch.randn((64, 3, 3, 64), device=dev)
-        K._winograd_weights(w, "h16")
 
 
 def cfg(opts=()):
