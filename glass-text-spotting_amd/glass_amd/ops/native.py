@@ -236,7 +236,10 @@ def _probe_desc(Cout: int, KH: int, KW: int, Cin: int) -> ConvDesc:
 
 
 def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str) -> list:
-    """which packed forms a [Cout,KH,KW,Cin] weight can be asked for under `precision` (the routing of conv2d_nhwc)"""
+    """which packed forms a [Cout,KH,KW,Cin] weight can be asked for under `precision` (the routing of conv2d_nhwc);
+    "all": every form the layer supports (micro-benchmarks that force kernels across precisions)"""
+    if precision == "all":
+        return pack_kinds(Cout, KH, KW, Cin, "fp32") + pack_kinds(Cout, KH, KW, Cin, "fp16")
     L, d = lib(), _probe_desc(Cout, KH, KW, Cin)
     kinds = []
     if precision == "fp32":

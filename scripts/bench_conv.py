@@ -53,7 +53,7 @@ for name, N, H, W, Cin, Cout, k, s, p in LAYERS:
     if only and only not in name:
         continue
     x = torch.randn((N, H, W, Cin), device=dev)
-    w = torch.randn((Cout, k, k, Cin), device=dev) * 0.05
+    w = K.prepare_conv_weights(torch.randn((Cout, k, k, Cin), device=dev) * 0.05, "all")     # packed once, like a loaded model's layer
     b = torch.randn((Cout,), device=dev)
     K.set_pointwise(False)
     y = K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, winograd=False)

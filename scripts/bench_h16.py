@@ -19,7 +19,7 @@ for name, N, H, W, Cin, Cout, k, res in LAYERS:
     if only and only not in name:
         continue
     x = torch.randn((N, H, W, Cin), device=dev).half()
-    w = torch.randn((Cout, k, k, Cin), device=dev) * 0.05
+    w = K.prepare_conv_weights(torch.randn((Cout, k, k, Cin), device=dev) * 0.05, "all")     # packed once, like a loaded model's layer
     b = torch.randn((Cout,), device=dev)
     y = torch.empty((N, H, W, Cout), device=dev, dtype=torch.float16)
     r = torch.randn((N, H, W, Cout), device=dev).half() if res else None

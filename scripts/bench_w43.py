@@ -11,7 +11,7 @@ LAYERS = [("fpn_out2 256@256 B8", 8, 256, 256, 256, 256), ("local l3 256@16x33 R
           ("local l1.0 32->64@64 R256", 256, 64, 64, 32, 64)]
 for name, N, H, W, Cin, Cout in LAYERS:
     x = torch.randn((N, H, W, Cin), device=dev)
-    w = torch.randn((Cout, 3, 3, Cin), device=dev) * 0.05
+    w = K.prepare_conv_weights(torch.randn((Cout, 3, 3, Cin), device=dev) * 0.05, "all")     # packed once, like a loaded model's layer
     b = torch.randn((Cout,), device=dev)
     y = torch.empty((N, H, W, Cout), device=dev)
     f = lambda: K.conv2d_nhwc(x, w, b, padding=1, relu=1, out=y, winograd="f43")
@@ -26,7 +26,7 @@ for name, N, H, W, Cin, Cout in LAYERS:
     print(f"ABL={os.environ.get('GLASS_W43_ABL', '0')} {name:28s} {ms:7.3f} ms  executed {ex / ms / 1e9:6.1f} TF/s ({ex / ms / 1e9 / 157.3:.3f} of peak)", flush=True)
 if os.environ.get("W43_RES"):
     for name, N, H, W, Cin, Cout in LAYERS[:2]:
-        x = torch.randn((N, H, W, Cin), device=dev); w = torch.randn((Cout, 3, 3, Cin), device=dev) * 0.05
+        x = torch.randn((N, H, W, Cin), device=dev); w = K.prepare_conv_weights(torch.randn((Cout, 3, 3, Cin), device=dev) * 0.05, "all")
         b = torch.randn((Cout,), device=dev); y = torch.empty((N, H, W, Cout), device=dev); r = torch.randn((N, H, W, Cout), device=dev)
         f = lambda: K.conv2d_nhwc(x, w, b, padding=1, relu=1, out=y, residual=r, res_mode=1, winograd="f43")
         f(); torch.cuda.synchronize()

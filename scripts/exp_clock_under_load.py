@@ -5,7 +5,7 @@ from glass_amd.ops import native as K
 dev = torch.device("cuda:0")
 mode = sys.argv[1]
 N, H, W, C = 8, 256, 256, 256
-w = torch.randn((C, 3, 3, C), device=dev) * 0.05
+w = K.prepare_conv_weights(torch.randn((C, 3, 3, C), device=dev) * 0.05, "all")
 b = torch.randn((C,), device=dev)
 if mode == "fp16":
     K.set_conv_precision("fp16s")

@@ -7,7 +7,7 @@ from glass_amd.ops import native as K
 N, H, W, Cin, Cout, k, s, p = [int(v) for v in sys.argv[1:9]]
 it = int(sys.argv[9]) if len(sys.argv) > 9 else 3
 dev = torch.device("cuda:0")
-x = torch.randn((N, H, W, Cin), device=dev); w = torch.randn((Cout, k, k, Cin), device=dev) * 0.05; b = torch.randn((Cout,), device=dev)
+x = torch.randn((N, H, W, Cin), device=dev); w = K.prepare_conv_weights(torch.randn((Cout, k, k, Cin), device=dev) * 0.05, "all"); b = torch.randn((Cout,), device=dev)
 y = K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1)
 for _ in range(it):
     K.conv2d_nhwc(x, w, b, stride=s, padding=p, relu=1, out=y)
