@@ -35,7 +35,13 @@ def _worker(rank, world, port, q):
     back = unpack_results(flat, [(100 + g, 200) for g in range(n_images)], 4, 26)
     ok = all(len(b) == g % 4 and (len(b) == 0 or float(b.pred_boxes.tensor[0, 0]) == float(g)) and
              (len(b) == 0 or int(b.pred_char_index[0, 0]) == 96) for g, b in enumerate(back))
-    q.put((rank, mine, ok))
+    # without `rows`, ranks that hold different record counts must all RAISE (count exchange), not hang or mis-view
+    raised = False
+    try:
+        all_gather_records(rec[: 2 + rank])
+    except ValueError as e:
+        raised = "different record counts" in str(e)
+    q.put((rank, mine, ok and raised))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -307,3 +307,44 @@ def test_mirror_into_detectron2_registers_our_classes(monkeypatch):
     assert mod.PROPOSAL_GENERATOR_REGISTRY.get("RotatedRPN") is R.PROPOSAL_GENERATOR_REGISTRY.get("RotatedRPN")
     assert mod.ROI_HEADS_REGISTRY.get("MaskRotatedRecognizerHybridHead") is R.ROI_HEADS_REGISTRY.get("MaskRotatedRecognizerHybridHead")
     assert R.mirror_into_detectron2() is True                             # idempotent
+
+
+def test_segment_scoped_forwards_close_and_throw_inside_the_scope():
+    """a step generator closed or thrown into at a yield runs its `finally` blocks (and sees the exception) at
+    once and INSIDE the enter()/leave() scope - not whenever the garbage collector finds it."""
+    from glass_amd.utils.pipeline import segment_scoped
+    state = {"depth": 0}
+    log = []
+
+    def enter():
+        state["depth"] += 1
+        return state["depth"]
+
+    def leave(tok):
+        state["depth"] -= 1
+
+    def body():
+        try:
+            x = yield "a"
+            log.append(("got", x, state["depth"]))
+            try:
+                yield "b"
+            except KeyError as e:
+                log.append(("caught", str(e), state["depth"]))
+                yield "c"
+            yield "d"
+        finally:
+            log.append(("finally", state["depth"]))
+
+    g = segment_scoped(body(), enter, leave)
+    assert next(g) == "a" and state["depth"] == 0
+    assert g.send(7) == "b" and log[-1] == ("got", 7, 1) and state["depth"] == 0
+    assert g.throw(KeyError("boom")) == "c" and log[-1] == ("caught", "'boom'", 1)
+    g.close()
+    assert log[-1] == ("finally", 1) and state["depth"] == 0
+    # an exception the body does not handle propagates, scope closed
+    g2 = segment_scoped(body(), enter, leave)
+    next(g2)
+    with pytest.raises(RuntimeError):
+        g2.throw(RuntimeError("x"))
+    assert state["depth"] == 0 and log[-1] == ("finally", 1)
