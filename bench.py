@@ -1,9 +1,11 @@
 #!/usr/bin/env python
 """bench.py — GLASS inference hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its N ranks itself (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   # or joins the world torchrun made
+It never runs fewer ranks than --gpus asks for: a node with fewer GPUs than N (RCCL backend) or a WORLD_SIZE that
+contradicts --gpus exits non-zero without printing a line.
 
 One "step" = one pass of the hot path (`GlassRCNN.inference`: preprocess -> ResNet-50+FPN ->
 rotated RPN -> box head -> rotated RoIAlign -> local extractor -> fusion attention -> recognizer
@@ -198,18 +200,42 @@ def cpu_baseline(cfg, sd, side, rois):
                                       f"median {med1:.2f} s (runs {', '.join(f'{t:.2f}' for t in ts1)} s)"}}
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (reference tools/eval_glass.py:199-206
+    `launch(main, num_gpus, ...)`), each a re-exec of this command with the torch.distributed.run environment, and return
+    their exit code.  Refuses - non-zero - when the node cannot give every rank its own GPU (RCCL needs one device per rank);
+    GLASS_BENCH_BACKEND=gloo lifts that check to exercise the N-rank plumbing on a 1-GPU box."""
+    from glass_amd.distributed import launch_local_ranks
+    backend = os.environ.get("GLASS_BENCH_BACKEND", "nccl")
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X (no CPU fallback for the product path)", file=sys.stderr)
+        return 2
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < args.gpus:
+        print(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible; RCCL needs one device per rank - refusing to run fewer "
+              f"ranks than asked (GLASS_BENCH_BACKEND=gloo exercises the {args.gpus}-rank path on fewer devices)", file=sys.stderr)
+        return 2
+    return launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))                       # this process only launches; the ranks print the line
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     ndev = torch.cuda.device_count()
     backend = os.environ.get("GLASS_BENCH_BACKEND", "nccl")     # "nccl" = RCCL over xGMI; "gloo" only to
-    dev_index = local_rank % ndev                                 # exercise the N>1 plumbing on a 1-GPU box
+    if backend == "nccl" and world > ndev:                        # exercise the N>1 plumbing on a 1-GPU box
+        raise SystemExit(f"WORLD_SIZE={world} ranks but {ndev} GPU(s) visible: RCCL needs one device per rank")
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -534,6 +560,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        assert line["n_gpus"] == args.gpus == line["comm"]["world_size"], (line["n_gpus"], args.gpus, line["comm"])
         print(json.dumps(line), flush=True)
 
 

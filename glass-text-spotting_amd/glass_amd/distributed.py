@@ -17,7 +17,12 @@ Full `[D,T,97]` probability tensors stay on the owning rank (1 MB/image; gather 
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+import os
+import socket
+import subprocess
+import sys
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -117,7 +122,7 @@ def unpack_words(rec: torch.Tensor, max_det: int, steps: int, characters: Sequen
     out = []
     D = max_det
     for i in range(rec.shape[0]):
-        k = int(rec[i, 0].item())
+        k = _record_count(rec, i)
         o = 1
         boxes = rec[i, o:o + 5 * D].view(D, 5)[:k]; o += 5 * D
         scores = rec[i, o:o + D][:k]; o += D
@@ -135,7 +140,7 @@ def unpack_results(rec: torch.Tensor, image_sizes: Sequence[Tuple[int, int]], ma
     out = []
     D = max_det
     for i, size in enumerate(image_sizes):
-        k = int(rec[i, 0].item())
+        k = _record_count(rec, i)
         o = 1
         r = Instances(tuple(size))
         r.pred_boxes = RotatedBoxes(rec[i, o:o + 5 * D].view(D, 5)[:k].clone()); o += 5 * D
@@ -172,13 +177,20 @@ def all_gather_records(local: torch.Tensor, group=None, rows: int = None) -> tor
     first exchange their row counts (one more tiny collective and a host read-back - pass `rows` on a hot path) and ALL of
     them raise if the counts differ, instead of hanging or mis-viewing inside the payload collective."""
     import torch.distributed as dist
+    oversize = None
     if rows is not None:
         if local.shape[0] > rows:
-            raise ValueError(f"all_gather_records: {local.shape[0]} local records > rows={rows}")
+            # raising HERE would leave the other ranks waiting inside the collective: take part with a truncated, poisoned
+            # shard (count -1 in every record: unpack_* raise on it on every rank) and raise after the collective has run
+            oversize = local.shape[0]
+            local = local[:rows].clone()
+            local[:, 0] = -1.0
         if local.shape[0] < rows:
             pad = torch.zeros((rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             local = torch.cat([local, pad], 0)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if oversize is not None:
+            raise ValueError(f"all_gather_records: {oversize} local records > rows={rows}")
         return local.unsqueeze(0)
     world = dist.get_world_size(group)
     if rows is None:
@@ -190,4 +202,81 @@ def all_gather_records(local: torch.Tensor, group=None, rows: int = None) -> tor
             raise ValueError(f"all_gather_records: ranks hold different record counts {counts}; pass rows=shard_rows(N, W)")
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)      # rank-major concatenation
+    if oversize is not None:
+        raise ValueError(f"all_gather_records: {oversize} local records > rows={rows} (the other ranks received this shard's "
+                         f"records with count -1 and raise when they unpack them)")
     return out.view((world,) + tuple(local.shape))
+
+
+def _record_count(rec: torch.Tensor, i: int) -> int:
+    k = int(rec[i, 0].item())
+    if k < 0:
+        raise ValueError(f"record {i} is poisoned (count {k}): the rank that owns it passed more records than `rows` to "
+                         f"all_gather_records")
+    return k
+
+
+# --------------------------------------------------------------------------- launching the ranks
+# The reference starts its ranks itself: tools/eval_glass.py:199-206 `launch(main, num_gpus, num_machines=1, machine_rank=0,
+# dist_url=..., args=(args,))` (detectron2.engine.launch: one process per GPU on this node, NCCL process group, then main()).
+# Same contract here without the pickled closure: re-exec a command once per rank with the torch.distributed.run
+# environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), so a script works identically under `torchrun` and
+# when it launches itself.
+
+def free_port(addr: str = "127.0.0.1") -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind((addr, 0))
+        return int(s.getsockname()[1])
+
+
+def rank_env(rank: int, world_size: int, port: int, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
+    """environment of local rank `rank` of a one-node job (what `python -m torch.distributed.run --nnodes=1` exports)"""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside [0, {world_size})")
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world_size), "LOCAL_WORLD_SIZE": str(world_size),
+                "GROUP_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL across processes needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")                      # torchrun's default for nproc > 1: the host side is launch glue
+    return env
+
+
+def launch_local_ranks(argv: Sequence[str], world_size: int, port: Optional[int] = None, base_env: Optional[Dict[str, str]] = None,
+                       poll_s: float = 0.05, grace_s: float = 5.0) -> int:
+    """Start `argv` once per rank (own session each, stdio inherited), wait for all of them; the first non-zero exit code
+    terminates the remaining ranks (SIGTERM to exactly the process groups started here, SIGKILL after `grace_s`) and is
+    returned - a rank that died must not leave the others waiting in a collective.  0 = every rank exited 0."""
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    port = free_port() if port is None else int(port)
+    procs = [subprocess.Popen(list(argv), env=rank_env(r, world_size, port, base_env), start_new_session=True)
+             for r in range(world_size)]
+    rc = 0
+    try:
+        live = set(range(world_size))
+        while live and rc == 0:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0:
+                        rc = code if code > 0 else 128 - code        # a signal -N reads as 128 + N, like a shell
+                        print(f"[launch_local_ranks] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                        break
+            if live and rc == 0:
+                time.sleep(poll_s)
+    finally:
+        import signal
+        for sig, wait in ((signal.SIGTERM, grace_s), (signal.SIGKILL, grace_s)):
+            left = [p for p in procs if p.poll() is None]
+            if not left:
+                break
+            for p in left:
+                try:
+                    os.killpg(p.pid, sig)                            # start_new_session: pgid == pid of the rank we started
+                except ProcessLookupError:
+                    pass
+            t_end = time.time() + wait
+            while time.time() < t_end and any(p.poll() is None for p in left):
+                time.sleep(poll_s)
+    return rc

@@ -23,10 +23,10 @@ tail -1 gpurun_out/bench_under_rocprof.log | cut -c1-300
 head -12 gpurun_out/kernel_stats_serial.txt | cut -c1-150
 cat gpurun_out/pmc_conv_summary.json | head -60
 # 4. optional: the N-rank bench line (one process per GPU over RCCL; on a 1-GPU box GLASS_BENCH_BACKEND=gloo puts every rank on
-#    device 0 and still exercises the sharding + all-gather path):  bash scripts/collect_profiles.sh 2
+#    device 0 and still exercises the sharding + all-gather path):  GLASS_BENCH_BACKEND=gloo bash scripts/collect_profiles.sh 2
 N=${1:-1}
 if [ "$N" -gt 1 ]; then
-  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port 29533 \
-    bench.py --gpus "$N" --steps 20 --warmup 3 --no-extras > gpurun_out/bench_${N}rank.json 2> gpurun_out/bench_${N}rank.log
+  # the driver-facing entry itself: bench.py starts its N ranks (glass_amd.distributed.launch_local_ranks), no torchrun
+  timeout 900 python bench.py --gpus "$N" --steps 20 --warmup 3 --no-extras > gpurun_out/bench_${N}rank.json 2> gpurun_out/bench_${N}rank.log
   python -c "import json,sys; d=json.load(open('gpurun_out/bench_${N}rank.json')); print({k: d[k] for k in ('value','n_gpus','ms_per_step','comm')})"
 fi
