@@ -348,7 +348,10 @@ __global__ __launch_bounds__(256) void dec_fc_att_kernel(DecParams p, const floa
   const int T = p.T, C = p.C;
 #pragma unroll
   for (int r = 0; r < DEC_RB; ++r) h[r][u] = (r < nr) ? hcur[(long)(r0 + r) * DEC_D + u] : 0.f;
-  if (u < DEC_RB) ycur[u] = (step == -1 || u >= nr) ? 0 : p.yprev[r0 + u];
+  // previous symbol: 0 ([GO]) before the first step; not read at all by an fc-only launch (do_att == 0: the beam-search entry
+  // points p.yprev at scratch it has not written yet); a caller-supplied symbol (glass_attention_decode_step) is clamped to
+  // the embedding table - an index outside [0, C) must not become an out-of-bounds read behind a C ABI
+  if (u < DEC_RB) ycur[u] = (step == -1 || u >= nr || !do_att) ? 0 : min(max(p.yprev[r0 + u], 0), C - 1);
   __syncthreads();
   if (step >= 0) {
     // ---- logits = fc(h) * temperature; softmax over C; argmax (first maximum)

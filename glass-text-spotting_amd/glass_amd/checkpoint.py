@@ -28,8 +28,9 @@ def load_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
 
 
 def fold_conv(sd: Dict[str, torch.Tensor], conv: str, norm: Optional[str], device, cin_pad: int = 4,
-              eps: float = BN_EPS) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """conv `conv`.weight[/bias] followed by eval-mode BatchNorm `norm`.* -> (w_khwc, bias)."""
+              eps: float = BN_EPS, stride=1) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """conv `conv`.weight[/bias] followed by eval-mode BatchNorm `norm`.* -> (w_khwc, bias).  `stride`: the layer's stride
+    when it is not 1 (a strided 3x3 layer gets no Winograd packs)."""
     w = sd[conv + ".weight"].double()
     b = sd[conv + ".bias"].double() if (conv + ".bias") in sd else None
     if norm is not None and (norm + ".weight") in sd:
@@ -42,16 +43,17 @@ def fold_conv(sd: Dict[str, torch.Tensor], conv: str, norm: Optional[str], devic
     cin4 = (cin + cin_pad - 1) // cin_pad * cin_pad
     out = torch.zeros((cout, kh, kw, cin4), dtype=torch.float32)
     out[..., :cin] = w.permute(0, 2, 3, 1).float()
-    return conv_weight(out, device), (None if b is None else b.float().contiguous().to(device))
+    return conv_weight(out, device, stride), (None if b is None else b.float().contiguous().to(device))
 
 
 def dev(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().float().contiguous().to(device)
 
 
-def conv_weight(w: torch.Tensor, device):
+def conv_weight(w: torch.Tensor, device, stride=1):
     """[Cout,KH,KW,Cin] (conv) or [Nout,K] (linear) -> ops.native.ConvWeight on `device`: the raw fp32 tensor plus every
     packed form the layer's kernels stream (Winograd U, pointwise / fp16 MFMA fragment order), built here, ONCE, for the conv
-    precision of the model being loaded (ops.native.packing_for).  CPU `device` (host-only tests): raw tensor only."""
+    routing of the model being loaded (ops.native.packing_for: its precision decides the forms, and the Routing itself is stamped
+    on the ConvWeight so that the layer's launches follow it).  CPU `device` (host-only tests): raw tensor only."""
     from .ops import native as K
-    return K.prepare_conv_weights(dev(w, device))
+    return K.prepare_conv_weights(dev(w, device), stride=stride)

@@ -75,7 +75,7 @@ class ResNetFPN(InferenceModule):
         """x: [N,Hp,Wp,4] normalised NHWC4 batch -> {p2..p6} NHWC tensors."""
         w = self.w
         # entry of the conv chain: in 'fp16s' mode the stem writes fp16 and every later conv / pool follows its input's dtype
-        x = K.conv2d_nhwc(x, *w["stem"], stride=2, padding=3, relu=1, out_dtype=K.act_dtype())
+        x = K.conv2d_nhwc(x, *w["stem"], stride=2, padding=3, relu=1, out_dtype=K.act_dtype(w["stem"][0]))
         x = K.maxpool2d_nhwc(x, 3, 2, 1)
         feats = {}
         for sname, nblk in _STAGES:

@@ -67,7 +67,7 @@ class ResNetFeatureExtractor(InferenceModule):
             # conv0_1 + conv0_2 + maxpool1 in one kernel (csrc/local_stem.hip): the 16- and 32-channel maps stay on the CU
             x = K.local_stem_fused(x, *w["conv0_1"], *w["conv0_2"])
         else:
-            x = K.conv2d_nhwc(x, *w["conv0_1"], padding=1, relu=1, out_dtype=K.act_dtype())      # entry of the fp16-storage chain
+            x = K.conv2d_nhwc(x, *w["conv0_1"], padding=1, relu=1, out_dtype=K.act_dtype(w["conv0_1"][0]))      # entry of the fp16-storage chain
             x = K.conv2d_nhwc(x, *w["conv0_2"], padding=1, relu=1)
         for li, nblk in _LAYERS:
             if li in pools and x.shape[0] > 0 and not (fused_stem and li == 1):

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 
 from ...utils.module import InferenceModule
-from ...utils.pipeline import ReadBack, StepOutput, drive, segment_scoped
+from ...utils.pipeline import ReadBack, StepOutput, drive
 
 from ...checkpoint import load_checkpoint_file
 from ...ops import native as K
@@ -45,6 +45,9 @@ class GeneralizedRCNN(InferenceModule):
         self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
         self.input_format = cfg.INPUT.FORMAT
         self.conv_precision = str(cfg.MODEL.CONV_PRECISION) if hasattr(cfg.MODEL, "CONV_PRECISION") else "fp32"
+        # kernel routing of THIS model (precision from the cfg, the A/B switches from the GLASS_* environment read here, once):
+        # stamped on every ConvWeight at load, read by the launches - nothing process-global (SURVEY 8b "Threading")
+        self.routing = K.Routing(precision=self.conv_precision)
         self._loaded = False
         # padded device-resident results of the most recent synchronous call.  With several steps in flight
         # (utils.pipeline.run_pipelined) read `.batch` of the step's own return value (pipeline.StepOutput) instead.
@@ -62,7 +65,7 @@ class GeneralizedRCNN(InferenceModule):
         # every conv / linear weight is re-laid AND packed for this model's conv precision here (checkpoint.conv_weight ->
         # ops.native.prepare_conv_weights): the packed tensors are owned by the layers, so they are freed with the model,
         # and ONE synchronisation at the end makes them visible to whatever streams the steps will run on
-        with K.packing_for(self.conv_precision):
+        with K.packing_for(self.routing):
             self.backbone.import_weights(state_dict, dev, "backbone.")
             self.proposal_generator.import_weights(state_dict, dev, "proposal_generator.")
             self.roi_heads.import_weights(state_dict, dev, "roi_heads.")
@@ -107,11 +110,9 @@ class GeneralizedRCNN(InferenceModule):
         assert not self.training
         if not self._loaded:
             raise RuntimeError("no weights loaded: call load_state_dict()/load_checkpoint() first")
-        # the conv precision is process-global state in ops.native: switch it per SEGMENT, never across a yield (the
-        # other in-flight steps of run_pipelined run between this generator's segments)
-        return (yield from segment_scoped(
-            self._inference_body_g(batched_inputs, detected_instances, do_postprocess, override_boxes),
-            lambda: K.set_conv_precision(self.conv_precision), K.set_conv_precision))
+        # (the conv precision travels with the layers' weights - ops.native.Routing - so steps of models of different
+        #  precision can interleave segment by segment, or run on different host threads, without any switching here)
+        return (yield from self._inference_body_g(batched_inputs, detected_instances, do_postprocess, override_boxes))
 
     def _trunk(self, nhwc4: torch.Tensor, hw: torch.Tensor) -> Dict[str, torch.Tensor]:
         """padded batch -> FPN features, RPN proposals and the box head's detections: every shape here follows from

@@ -9,6 +9,7 @@ import collections
 import ctypes
 import math
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -81,72 +82,128 @@ def conv_out_size(H, W, KH, KW, stride, padding):
     return (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
 
 
-# Process-wide kernel routing switches (env GLASS_*: experiments / A-B runs).  Packed weights are NOT kept here: they belong
-# to the layer that owns them (class ConvWeight below, built once at load by prepare_conv_weights).
-_WINO = {"enabled": os.environ.get("GLASS_WINOGRAD", "1") != "0", "on_the_fly": 0,
-         "f43": os.environ.get("GLASS_WINOGRAD43", "1") != "0", "pw": {"0": False, "all": "all"}.get(os.environ.get("GLASS_POINTWISE", "1"), True),
-         "precision": os.environ.get("GLASS_CONV_PRECISION", "fp32"), "h16": os.environ.get("GLASS_CONV_H16", "1") != "0",
-         "load_precision": None}
+_PRECISIONS = ("fp32", "fp16", "fp16s")
+
+
+class Routing:
+    """Which kernel a conv / linear launch takes, as VALUES that travel with the layer (no global state, re-entrant
+    per model): a model builds one `Routing` at construction (environment variables GLASS_* give the defaults, `MODEL.
+    CONV_PRECISION` the precision), `load_state_dict` stamps it on every `ConvWeight` it packs (`packing_for`), and
+    `conv2d_nhwc` reads the routing OF THE WEIGHT IT IS HANDED - two models of different precision can be driven from two host
+    threads, or interleaved segment by segment by `run_pipelined`, without touching anything shared.
+      precision   'fp32' (the reference's arithmetic: fp32 MFMA / Winograd), 'fp16' (operands rounded to fp16, fp16 MFMA, fp32
+                  accumulate, fp32 storage) or 'fp16s' (the same arithmetic, conv-path activations STORED as fp16; configs[4])
+      winograd    eligible 3x3 / stride-1 layers take the Winograd kernels (GLASS_WINOGRAD=0: direct kernel everywhere)
+      f43         ... F(4x4,3x3) where it pays (GLASS_WINOGRAD43=0: F(2x2,3x3) only)
+      pw          the weight-streaming 1x1 kernel: True (the end-to-end rule), False, or "all" (every supported layer)
+      h16         fp16 modes: the packed-weight fp16-MFMA kernel (GLASS_CONV_H16=0: fp32 template with fp16 operands)
+      local_stem  the fused conv0_1 + conv0_2 + maxpool kernel of the local extractor (GLASS_LOCAL_STEM=0: three launches)"""
+    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem")
+
+    def __init__(self, precision: Optional[str] = None, winograd: Optional[bool] = None, f43: Optional[bool] = None, pw=None,
+                 h16: Optional[bool] = None, local_stem: Optional[bool] = None):
+        e = os.environ.get
+        self.precision = precision or e("GLASS_CONV_PRECISION", "fp32")
+        if self.precision not in _PRECISIONS:
+            raise GlassLibraryError(f"unknown conv precision {self.precision!r}")
+        self.winograd = (e("GLASS_WINOGRAD", "1") != "0") if winograd is None else bool(winograd)
+        self.f43 = (e("GLASS_WINOGRAD43", "1") != "0") if f43 is None else bool(f43)
+        self.pw = {"0": False, "all": "all"}.get(e("GLASS_POINTWISE", "1"), True) if pw is None else (pw if pw == "all" else bool(pw))
+        self.h16 = (e("GLASS_CONV_H16", "1") != "0") if h16 is None else bool(h16)
+        self.local_stem = (e("GLASS_LOCAL_STEM", "1") != "0") if local_stem is None else bool(local_stem)
+
+    def replace(self, **kw) -> "Routing":
+        r = Routing.__new__(Routing)
+        for k in Routing.__slots__:
+            setattr(r, k, kw.pop(k, getattr(self, k)))
+        if kw:
+            raise TypeError(f"unknown routing fields {sorted(kw)}")
+        if r.precision not in _PRECISIONS:
+            raise GlassLibraryError(f"unknown conv precision {r.precision!r}")
+        return r
+
+    @property
+    def act_dtype(self) -> torch.dtype:
+        """storage dtype the modules request for conv-path activations: float16 in 'fp16s' mode, else float32"""
+        return torch.float16 if self.precision == "fp16s" else torch.float32
+
+    def __repr__(self):
+        return "Routing(" + ", ".join(f"{k}={getattr(self, k)!r}" for k in Routing.__slots__) + ")"
+
+
+# The routing of launches that are handed RAW tensors (tests, micro-benchmarks, scripts/): the set_*() functions below edit
+# it.  A model's layers never read it - their ConvWeight carries the model's own Routing.
+_DEFAULT = Routing()
+_TLS = threading.local()                   # per host thread: .last_path (diagnostic), .load (the enclosing packing_for)
+_COUNTS = {"on_the_fly": 0}
+
+
+def default_routing() -> Routing:
+    return _DEFAULT
+
+
+def routing_of(w) -> Routing:
+    """the Routing a launch with weight `w` follows: the one stamped on its ConvWeight at load, else the raw-tensor default"""
+    r = getattr(w, "routing", None)
+    return r if r is not None else _DEFAULT
 
 
 def set_conv_precision(precision: str) -> str:
-    """'fp32' (default; the reference's arithmetic, fp32 MFMA / Winograd), 'fp16' (operands rounded to fp16, fp16 MFMA
-    with fp32 accumulation, direct kernel only - Winograd's transforms are not fp16 safe; activations stay fp32 in HBM)
-    or 'fp16s' (the same arithmetic with the conv-path activations STORED as fp16: the modules ask their entry convs for
-    fp16 outputs, every conv / max-pool / RoIAlign then follows its input's dtype; BASELINE configs[4]).
+    """Precision of launches on RAW tensors / ConvWeights prepared outside a model load (tests, scripts): 'fp32', 'fp16' or
+    'fp16s' (see Routing).  Models are not affected: their precision is `MODEL.CONV_PRECISION`, carried by their weights.
     `GLASS_CONV_PRECISION` sets the initial value.  Returns the previous setting."""
-    if precision not in ("fp32", "fp16", "fp16s"):
+    if precision not in _PRECISIONS:
         raise GlassLibraryError(f"unknown conv precision {precision!r}")
-    prev = _WINO["precision"]
-    _WINO["precision"] = precision
+    prev = _DEFAULT.precision
+    _DEFAULT.precision = precision
     return prev
 
 
 def conv_precision() -> str:
-    return _WINO["precision"]
+    return _DEFAULT.precision
 
 
-def act_dtype() -> torch.dtype:
-    """storage dtype the modules request for conv-path activations: float16 in 'fp16s' mode, else float32"""
-    return torch.float16 if _WINO["precision"] == "fp16s" else torch.float32
+def act_dtype(w=None) -> torch.dtype:
+    """storage dtype for conv-path activations under the routing of weight `w` (None: the raw-tensor default)"""
+    return routing_of(w).act_dtype
 
 
 def last_conv_path() -> str:
     """'pointwise' (conv1x1_pw_f32), 'winograd43' (conv3x3_wino43_f32), 'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct', 'direct_fp16' (fp32 template, fp16 operands) or 'packed_fp16' (conv_h16_kernel): which kernel
-    the most recent conv2d_nhwc call launched (bench/profiling aid)."""
-    return _WINO.get("last_path", "direct")
+    the most recent conv2d_nhwc call OF THIS HOST THREAD launched (bench/profiling aid)."""
+    return getattr(_TLS, "last_path", "direct")
 
 
 def set_winograd(enabled: bool) -> bool:
-    """Route eligible 3x3 convolutions through glass_conv3x3_winograd_nhwc (default on; GLASS_WINOGRAD=0 turns
-    it off).  Returns the previous setting."""
-    prev = _WINO["enabled"]
-    _WINO["enabled"] = bool(enabled)
+    """raw-tensor default: route eligible 3x3 convolutions through glass_conv3x3_winograd_nhwc (default on; GLASS_WINOGRAD=0
+    turns it off).  Returns the previous setting."""
+    prev = _DEFAULT.winograd
+    _DEFAULT.winograd = bool(enabled)
     return prev
 
 
 def set_winograd43(enabled: bool) -> bool:
-    """Let eligible layers (Cout % 128 == 0, Cin % 32 == 0, see _use_f43) take the F(4x4,3x3) kernel (default on;
-    GLASS_WINOGRAD43=0 turns it off: F(2x2,3x3) everywhere).  Returns the previous setting."""
-    prev = _WINO["f43"]
-    _WINO["f43"] = bool(enabled)
+    """raw-tensor default: let eligible layers (Cout % 128 == 0, Cin % 32 == 0, see _use_f43) take the F(4x4,3x3) kernel
+    (default on; GLASS_WINOGRAD43=0 turns it off: F(2x2,3x3) everywhere).  Returns the previous setting."""
+    prev = _DEFAULT.f43
+    _DEFAULT.f43 = bool(enabled)
     return prev
 
 
 def set_conv_h16(enabled: bool) -> bool:
-    """Let fp16-input convolutions with Cin % 64 == 0 and Cout % 64 == 0 take the packed-weight fp16 kernel
+    """raw-tensor default: let fp16-input convolutions with Cin % 64 == 0 and Cout % 64 == 0 take the packed-weight fp16 kernel
     (glass_conv2d_nhwc_h16_packed; default on, GLASS_CONV_H16=0: the fp32 template with fp16 operands everywhere).
     Returns the previous setting."""
-    prev = _WINO["h16"]
-    _WINO["h16"] = bool(enabled)
+    prev = _DEFAULT.h16
+    _DEFAULT.h16 = bool(enabled)
     return prev
 
 
 def set_pointwise(enabled: bool) -> bool:
-    """Let eligible 1x1 convolutions (Cin % 32 == 0, Cout % 128 == 0) take the weight-streaming GEMM kernel (default on;
-    GLASS_POINTWISE=0: the implicit-GEMM kernel everywhere).  Returns the previous setting."""
-    prev = _WINO["pw"]
-    _WINO["pw"] = enabled if enabled == "all" else bool(enabled)      # "all": every supported layer (tests, micro-benchmarks)
+    """raw-tensor default: let eligible 1x1 convolutions (Cin % 32 == 0, Cout % 128 == 0) take the weight-streaming GEMM kernel
+    (default on; GLASS_POINTWISE=0: the implicit-GEMM kernel everywhere).  Returns the previous setting."""
+    prev = _DEFAULT.pw
+    _DEFAULT.pw = enabled if enabled == "all" else bool(enabled)      # "all": every supported layer (tests, micro-benchmarks)
     return prev
 
 
@@ -189,12 +246,17 @@ class ConvWeight:
     takes) plus the packed forms the other kernels stream (`packs`: False -> F(2x2,3x3) U, True -> F(4x4,3x3) U, "pw" ->
     fragment-ordered 1x1 weights, "h16" -> fp16 fragment-ordered weights), built ONCE by prepare_conv_weights when the
     checkpoint is loaded and owned by the layer: they live and die with the model, no global cache, no first-launch
-    synchronisation, nothing keyed by a device address (checkpoint row)."""
-    __slots__ = ("raw", "packs")
+    synchronisation, nothing keyed by a device address (checkpoint row).  `routing`: the owning model's
+    Routing (None for weights prepared outside a model load: such launches follow the raw-tensor default).  `version` is
+    `raw._version` at packing time: an in-place edit of `raw` afterwards (weight surgery, `copy_`) makes `_packed` re-pack
+    instead of streaming stale packs."""
+    __slots__ = ("raw", "packs", "routing", "version")
 
-    def __init__(self, raw: torch.Tensor):
+    def __init__(self, raw: torch.Tensor, routing: Optional[Routing] = None):
         self.raw = _f32c(raw, "w")
         self.packs = {}
+        self.routing = routing
+        self.version = raw._version
 
     @property
     def shape(self):
@@ -209,22 +271,21 @@ class ConvWeight:
 
 
 class packing_for:
-    """`with packing_for(precision):` around a model's import_weights: prepare_conv_weights packs for THAT conv precision
-    ('fp32': Winograd / pointwise forms, 'fp16' / 'fp16s': the fp16 fragment form) and skips its per-call stream
-    synchronisation - the caller synchronises once when every layer is packed (GeneralizedRCNN.load_state_dict)."""
+    """`with packing_for(routing):` around a model's import_weights (this host thread): prepare_conv_weights packs for THAT
+    routing's precision ('fp32': Winograd / pointwise forms, 'fp16' / 'fp16s': the fp16 fragment form), stamps the routing on
+    every ConvWeight it builds, and skips its per-call stream synchronisation - the caller synchronises once when every layer
+    is packed (GeneralizedRCNN.load_state_dict).  A plain precision string is accepted for a default-switch Routing."""
 
-    def __init__(self, precision: str):
-        if precision not in ("fp32", "fp16", "fp16s"):
-            raise GlassLibraryError(f"unknown conv precision {precision!r}")
-        self.precision = precision
+    def __init__(self, routing):
+        self.routing = routing if isinstance(routing, Routing) else Routing(precision=routing)
 
     def __enter__(self):
-        self.prev = _WINO["load_precision"]
-        _WINO["load_precision"] = self.precision
+        self.prev = getattr(_TLS, "load", None)
+        _TLS.load = self.routing
         return self
 
     def __exit__(self, *exc):
-        _WINO["load_precision"] = self.prev
+        _TLS.load = self.prev
         return False
 
 
@@ -235,15 +296,16 @@ def _probe_desc(Cout: int, KH: int, KW: int, Cin: int) -> ConvDesc:
     return ConvDesc(1, 16, 16, Cin, Cout, KH, KW, 1, 1, ph, pw, 16 + 2 * ph - KH + 1, 16 + 2 * pw - KW + 1, Cin, Cout, 0, 1, 0, 0, 0)
 
 
-def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str) -> list:
+def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str, stride=1, hint_hw: Optional[Tuple[int, int]] = None) -> list:
     """which packed forms a [Cout,KH,KW,Cin] weight can be asked for under `precision` (the routing of conv2d_nhwc);
-    "all": every form the layer supports (micro-benchmarks that force kernels across precisions)"""
+    "all": every form the layer supports (micro-benchmarks that force kernels across precisions).  `stride` != 1 rules the
+    Winograd forms out (stride-2 3x3 layers were carrying 52/9 of their size in packs no launch could take)."""
     if precision == "all":
-        return pack_kinds(Cout, KH, KW, Cin, "fp32") + pack_kinds(Cout, KH, KW, Cin, "fp16")
+        return pack_kinds(Cout, KH, KW, Cin, "fp32", stride) + pack_kinds(Cout, KH, KW, Cin, "fp16", stride)
     L, d = lib(), _probe_desc(Cout, KH, KW, Cin)
     kinds = []
     if precision == "fp32":
-        if KH == 3 and KW == 3:
+        if KH == 3 and KW == 3 and _pair(stride) == (1, 1):
             if L.glass_winograd_supported(ctypes.byref(d)):
                 kinds.append(False)
             if L.glass_winograd43_supported(ctypes.byref(d)):
@@ -255,53 +317,69 @@ def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str) -> list:
     return kinds
 
 
-def prepare_conv_weights(w: torch.Tensor, precision: Optional[str] = None) -> ConvWeight:
+def prepare_conv_weights(w: torch.Tensor, precision: Optional[str] = None, stride=1) -> ConvWeight:
     """w [Cout,KH,KW,Cin] (or [Nout,K] for a linear layer) fp32 on the device -> ConvWeight with every packed form its layer
-    can be routed to under `precision` (default: the enclosing packing_for(), else the current conv precision).  Load-time
-    plumbing: ~10 pack kernels per MB of weights, once per model."""
+    can be routed to under `precision` (default: the enclosing packing_for(), else the raw-tensor default precision).
+    `stride`: the layer's stride when the caller knows it (a stride-2 3x3 layer needs no Winograd form).  Load-time plumbing:
+    ~10 pack kernels per MB of weights, once per model."""
     if isinstance(w, ConvWeight):
         return w
     if w.dim() == 2:
         w = w.view(w.shape[0], 1, 1, w.shape[1])
-    cw = ConvWeight(w)
-    in_load = _WINO["load_precision"] is not None
-    precision = precision or _WINO["load_precision"] or _WINO["precision"]
+    load = getattr(_TLS, "load", None)
+    cw = ConvWeight(w, routing=load)
+    precision = precision or (load.precision if load is not None else _DEFAULT.precision)
     Cout, KH, KW, Cin = w.shape
     if w.is_cuda:
-        for kind in pack_kinds(Cout, KH, KW, Cin, precision):
+        for kind in pack_kinds(Cout, KH, KW, Cin, precision, stride):
             cw.packs[kind] = winograd_pack(w, kind)
-        if cw.packs and not in_load:
+        if cw.packs and load is None:
             torch.cuda.current_stream().synchronize()      # other streams (pipelined steps) may launch with it next
     return cw
 
 
 def packs_on_the_fly() -> int:
-    """how many conv launches had to pack their weights at launch time (a raw tensor instead of a ConvWeight, or a ConvWeight
-    prepared for another precision): 0 on the model path - tests assert it"""
-    return _WINO["on_the_fly"]
+    """how many conv launches had to pack their weights at launch time (a raw tensor instead of a ConvWeight, a ConvWeight
+    prepared for another precision, or one whose raw tensor was edited in place after packing): 0 on the model path - tests
+    assert it.  Raw-tensor callers that launch the same layer repeatedly should call prepare_conv_weights once."""
+    return _COUNTS["on_the_fly"]
 
 
 def _packed(w, wt: torch.Tensor, kind) -> torch.Tensor:
     if isinstance(w, ConvWeight):
+        if w.version != wt._version:
+            # `raw` was written in place since it was packed: every pack is stale.  Re-pack the forms the layer had, on this
+            # launch's stream (stream order covers this launch; a caller that edits weights while OTHER streams are launching
+            # with them has to synchronise itself, as with any tensor)
+            for k in list(w.packs):
+                w.packs[k] = winograd_pack(wt, k)
+            w.version = wt._version
+            _COUNTS["on_the_fly"] += 1
         u = w.packs.get(kind)
         if u is not None:
             return u
     # raw tensors (tests, micro-benchmarks) and layers prepared for another precision: pack for this launch only - same
     # stream as the launch, so stream order is all the synchronisation it needs, and nothing outlives the call
-    _WINO["on_the_fly"] += 1
+    _COUNTS["on_the_fly"] += 1
     return winograd_pack(wt, kind)
 
 
 def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stride=1, padding=0,
                 relu: int = 0, residual: Optional[torch.Tensor] = None, res_mode: int = 0,
                 out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cstride: int = 1,
-                cin: Optional[int] = None, winograd: Optional[bool] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+                cin: Optional[int] = None, winograd: Optional[bool] = None, out_dtype: Optional[torch.dtype] = None,
+                precision: Optional[str] = None, routing: Optional[Routing] = None) -> torch.Tensor:
     """y = act(conv(x, w) + bias [+ residual]).  x [N,H,W,ldx] NHWC, w [Cout,KH,KW,Cin]: a ConvWeight (the model path: packed
     forms built at load) or a plain device tensor (packed per launch where the chosen kernel needs it).
     3x3/stride 1/pad 1 layers that glass_winograd_supported() accepts go through the Winograd kernel
-    (winograd=None: follow set_winograd() / set_winograd43(); True/False force F(2x2,3x3) on / off for this call,
-    "f43" forces the F(4x4,3x3) kernel)."""
+    (winograd=None: follow the routing; True/False force F(2x2,3x3) on / off for this call, "f43" forces the F(4x4,3x3)
+    kernel).  Which kernel runs is decided by `routing` (default: the Routing stamped on `w` at model load, else the
+    raw-tensor default) with `precision` overriding its precision for this call - nothing process-global is read for a
+    model's layers."""
     wt = w.raw if isinstance(w, ConvWeight) else _f32c(w, "w")
+    rt = routing if routing is not None else routing_of(w)
+    if precision is not None and precision != rt.precision:
+        rt = rt.replace(precision=precision)
     _fhc(x, "x")
     N, H, W, ldx = x.shape
     Cout, KH, KW, Cin = wt.shape
@@ -330,7 +408,7 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
         _fhc(residual, "residual")
     def launch(entry: str, path: str, xt: torch.Tensor, weights: torch.Tensor, flags: Optional[int] = None) -> torch.Tensor:
         """one conv entry of the library: (desc, x, w | packed weights, bias, residual, y[, flags], stream)"""
-        _WINO["last_path"] = path
+        _TLS.last_path = path
         args = [ctypes.byref(d), c_void_p(_dev(xt, "x")), c_void_p(_dev(weights, "w")),
                 c_void_p(_dev(bias, "bias") if bias is not None else None),
                 c_void_p(_dev(residual, "residual") if residual is not None else None), c_void_p(_dev(out, "out"))]
@@ -341,21 +419,21 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
 
     any_half = x.dtype == torch.float16 or out.dtype == torch.float16 or (residual is not None and residual.dtype == torch.float16)
     if any_half:
-        if _WINO["precision"] != "fp16s" or winograd:
+        if rt.precision != "fp16s" or winograd:
             raise GlassLibraryError("float16 activation tensors need conv precision 'fp16s' (and no forced Winograd)")
         flags = (1 if x.dtype == torch.float16 else 0) | (2 if out.dtype == torch.float16 else 0) | \
                 (4 if residual is not None and residual.dtype == torch.float16 else 0)
         # fp16 input, Cin / Cout multiples of 64: the kernel built for the fp16 matrix cores (csrc/conv_h16.hip, weights
         # pre-rounded and packed once); everything else - fp32 entries, the 4/16/32-channel first layers, the narrow heads -
         # stays on the fp32 template with fp16 operands
-        if _WINO["h16"] and lib().glass_conv_h16_supported(ctypes.byref(d), int(flags)):
+        if rt.h16 and lib().glass_conv_h16_supported(ctypes.byref(d), int(flags)):
             return launch("glass_conv2d_nhwc_h16_packed", "packed_fp16", x, _packed(w, wt, "h16"), flags)
         return launch("glass_conv2d_nhwc_h16", "direct_fp16", x, wt, flags)
-    if _WINO["precision"] in ("fp16", "fp16s") and not winograd:
+    if rt.precision in ("fp16", "fp16s") and not winograd:
         # fp32 tensors in an fp16 mode (every layer of 'fp16', the fp32-input layers of 'fp16s': fusion conv, fc1 / fc2): where
         # a conv does enough work per input element, round the input to fp16 ONCE (glass_cast_f32_to_f16 - the rounding the
         # template applies while staging) and run the fp16-MFMA kernel on it; fp32 output and residual as they are
-        if (_WINO["h16"] and KH * KW * Cout >= 512 and x.numel() > 0 and
+        if (rt.h16 and KH * KW * Cout >= 512 and x.numel() > 0 and
                 lib().glass_conv_h16_supported(ctypes.byref(d), 1)):
             xh = torch.empty(x.shape, dtype=torch.float16, device=x.device)
             check(lib().glass_cast_f32_to_f16(c_void_p(_dev(x, "x")), c_void_p(_dev(xh)), ctypes.c_int64(x.numel()),
@@ -367,15 +445,15 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     # behind on 128->512 x0.92 and 64->256 x0.87), but routing the narrow / small ones to it (Cout 128, 8192-pixel maps)
     # LOWERS the end-to-end rate: 274.1 images/s with this rule, 271 without the kernel, 267 with "Cin >= 256, >= 8192
     # pixels" (three alternating runs each, same box)
-    if (winograd is None and _WINO["pw"] and KH == 1 and KW == 1 and (_WINO["pw"] == "all" or (Cin >= 256 and Cout >= 256 and N * Ho * Wo >= 16384))
+    if (winograd is None and rt.pw and KH == 1 and KW == 1 and (rt.pw == "all" or (Cin >= 256 and Cout >= 256 and N * Ho * Wo >= 16384))
             and lib().glass_pointwise_supported(ctypes.byref(d))):
         return launch("glass_conv1x1_pointwise_nhwc", "pointwise", x, _packed(w, wt, "pw"))
-    use_wino = _WINO["enabled"] if winograd is None else winograd
+    use_wino = rt.winograd if winograd is None else winograd
     if winograd is None and use_wino and KH == 3:
         # the Winograd kernel runs one 64-tile x 64-channel workgroup per CU: below ~96 workgroups (FPN p6, batch-2 res5)
         # the direct kernel's smaller tiles fill the chip better (measured 0.68-0.82x vs 1.15x at 128 workgroups)
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
-    f43 = winograd == "f43" or (winograd is None and _WINO["f43"] and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin))
+    f43 = winograd == "f43" or (winograd is None and rt.f43 and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin))
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
         return launch("glass_conv3x3_winograd43_nhwc", "winograd43", x, _packed(w, wt, True))
     if winograd == "f43":
@@ -389,11 +467,11 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
 
 
 def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, relu: int = 0,
-           out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, precision: Optional[str] = None) -> torch.Tensor:
     """x [M,K] @ w[Nout,K]^T + bias on the same MFMA kernel (H = W = KH = KW = 1)."""
     M, K = x.shape
     y = conv2d_nhwc(x.view(M, 1, 1, K), w if isinstance(w, ConvWeight) else w.view(w.shape[0], 1, 1, K), bias, relu=relu,
-                    out=None if out is None else out.view(M, 1, 1, -1), out_dtype=out_dtype)
+                    out=None if out is None else out.view(M, 1, 1, -1), out_dtype=out_dtype, precision=precision)
     return y.view(M, -1)
 
 
@@ -404,8 +482,9 @@ def _raw(w) -> torch.Tensor:
 def local_stem_supported(x: torch.Tensor, w1, w2) -> bool:
     """the fused conv0_1 + conv0_2 + maxpool kernel takes fp32 NHWC4 crops with H, W multiples of 32 (precision fp32, or
     fp16s: the fp16-storage arithmetic, fp16 output)"""
+    rt = routing_of(w1)
     w1, w2 = _raw(w1), _raw(w2)
-    return (_WINO["precision"] in ("fp32", "fp16s") and os.environ.get("GLASS_LOCAL_STEM", "1") != "0" and x.dtype == torch.float32 and
+    return (rt.precision in ("fp32", "fp16s") and rt.local_stem and x.dtype == torch.float32 and
             x.dim() == 4 and x.shape[-1] == 4 and tuple(w1.shape) == (16, 3, 3, 4) and tuple(w2.shape) == (32, 3, 3, 16) and
             bool(lib().glass_local_stem_supported(int(x.shape[1]), int(x.shape[2]))))
 
@@ -413,11 +492,11 @@ def local_stem_supported(x: torch.Tensor, w1, w2) -> bool:
 def local_stem_fused(x: torch.Tensor, w1, b1: torch.Tensor, w2, b2: torch.Tensor) -> torch.Tensor:
     """x [R,H,W,4] -> maxpool2x2(relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2)) [R,H/2,W/2,32] in one kernel; in 'fp16s'
     mode with the fp16 roundings of the unfused fp16-storage chain and an fp16 output."""
+    h16 = routing_of(w1).precision == "fp16s"
     w1, w2 = _raw(w1), _raw(w2)
     for t, n in ((x, "x"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
         _f32c(t, n)
     R, H, W, _ = x.shape
-    h16 = _WINO["precision"] == "fp16s"
     y = torch.empty((R, H // 2, W // 2, 32), dtype=torch.float16 if h16 else torch.float32, device=x.device)
     fn = lib().glass_local_stem_fused_h16 if h16 else lib().glass_local_stem_fused
     check(fn(c_void_p(_dev(x)), c_void_p(_dev(w1)), c_void_p(_dev(b1)), c_void_p(_dev(w2)), c_void_p(_dev(b2)), c_void_p(_dev(y)),

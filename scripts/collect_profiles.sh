@@ -18,7 +18,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; d
   GLASS_SINGLE_STREAM=1 timeout 500 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$tag -o pmc -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --pipeline 1 > gpurun_out/pmc_$tag.log 2>&1
   python scripts/pmc_summary.py "$(find /tmp/pmc_$tag -name '*.db' | head -1)" > gpurun_out/pmc_$tag.json
 done
-python scripts/pmc_make_summary.py gpurun_out/pmc_FETCH_SIZE.json gpurun_out/pmc_WRITE_SIZE.json gpurun_out/pmc_SQ_VALU_MFMA_BUSY_CYCLES.json > gpurun_out/pmc_conv_summary.json
+python scripts/pmc_make_summary.py gpurun_out/pmc_FETCH_SIZE.json gpurun_out/pmc_WRITE_SIZE.json gpurun_out/pmc_SQ_VALU_MFMA_BUSY_CYCLES.json gpurun_out/kernel_stats_serial.txt > gpurun_out/pmc_conv_summary.json
 tail -1 gpurun_out/bench_under_rocprof.log | cut -c1-300
 head -12 gpurun_out/kernel_stats_serial.txt | cut -c1-150
 cat gpurun_out/pmc_conv_summary.json | head -60

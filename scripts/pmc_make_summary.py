@@ -1,7 +1,7 @@
 """Fold the three rocprofv3 --pmc passes (scripts/pmc_summary.py outputs) into profiles/r01_pmc_conv_summary.json.
 
     python scripts/pmc_make_summary.py gpurun_out/pmc_FETCH_SIZE.json gpurun_out/pmc_WRITE_SIZE.json \
-        gpurun_out/pmc_MFMA.json > profiles/r01_pmc_conv_summary.json
+        gpurun_out/pmc_MFMA.json [gpurun_out/kernel_stats_serial.txt] > profiles/rNN_pmc_conv_summary.json
 
 Per MFMA kernel: HBM bytes per launch = 2 x FETCH_SIZE KB (gfx950 under-reports 16-byte/lane streaming reads by
 2x, MI355X_MICROARCH.md HBM section; checked on this path against maxpool_nhwc_kernel whose traffic is known)
@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from glass_amd._lib import source_sha16  # noqa: E402
 
 fetch, write, mfma = (json.load(open(p)) for p in sys.argv[1:4])
+stats_txt = sys.argv[4] if len(sys.argv) > 4 else None        # kernel_stats_serial.txt of the same library (optional)
 KEYS = {"conv3x3_wino43_f32": "conv3x3_wino43_f32", "conv1x1_pw_f32": "conv1x1_pw_f32", "conv3x3_wino128_f32": "conv3x3_wino128_f32", "conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, 1",
         "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, 1",
         "conv_igemm_f32_128x64": "conv_igemm_f32<2, 2, 2, 1, 1, 4, 32, 1",
@@ -22,17 +23,36 @@ KEYS = {"conv3x3_wino43_f32": "conv3x3_wino43_f32", "conv1x1_pw_f32": "conv1x1_p
 
 
 def pick(js, sub, counter):
-    for r in js["per_kernel"]:
-        if sub in r["kernel"] and "true>" not in r["kernel"] and r["counter"] == counter:   # "true>" = the fp16 instantiation
-            return r
-    return None
+    """every instantiation of the family (e.g. the wide AND the narrow shape of conv3x3_wino43_f32) folded into one row:
+    counter sums and sample counts add, the mean is per dispatch over all of them - the figure bench.py's per-family
+    `roofline.frac` is compared with"""
+    rows = [r for r in js["per_kernel"] if sub in r["kernel"] and "true>" not in r["kernel"] and r["counter"] == counter]
+    if not rows:                                                                            # "true>" = the fp16 instantiation
+        return None
+    tot, n = sum(r["sum"] for r in rows), sum(r["samples"] for r in rows)
+    return {"kernel": " | ".join(sorted({r["kernel"] for r in rows})), "sum": tot, "samples": n, "mean_per_dispatch": tot / n,
+            "instantiations": len({r["kernel"] for r in rows})}
 
 
 def ndisp(js, sub):
-    for r in js.get("dispatches", []):
-        if sub in r["kernel"] and "true>" not in r["kernel"]:
-            return r["n"], r["total_ns"]
-    return None, None
+    rows = [r for r in js.get("dispatches", []) if sub in r["kernel"] and "true>" not in r["kernel"]]
+    if not rows:
+        return None, None
+    return sum(r["n"] for r in rows), sum(r["total_ns"] for r in rows)
+
+
+def kernel_stats(path, sub):
+    """weighted average launch duration of the family in a scripts/prof_summary.py table (rocprofv3 --kernel-trace --stats of
+    the serial bench): sum of TotalDurationNs / sum of Calls over its instantiations"""
+    calls = tot = 0
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#") or line.startswith("Name") or sub not in line or "true>" in line:
+                continue
+            cols = line[72:].split()
+            calls += int(cols[0])
+            tot += int(cols[1])
+    return (calls, tot / calls / 1e3) if calls else (0, None)
 
 
 out = {"lib_source_sha16": source_sha16(),      # bench.py reports these counters only for the library they were taken with
@@ -50,11 +70,14 @@ for key, sub in KEYS.items():
         continue
     n, tot_ns = ndisp(mfma, sub)
     busy_per_launch = b["sum"] / n if n else None
-    ent = {"kernel": f["kernel"], "dispatches_sampled": n,
+    ent = {"kernel": f["kernel"], "instantiations": f["instantiations"], "dispatches_sampled": n,
            "FETCH_SIZE_KB_per_launch_raw": f["mean_per_dispatch"], "WRITE_SIZE_KB_per_launch_raw": w["mean_per_dispatch"],
            "hbm_bytes_per_launch_corrected": 1024.0 * (2.0 * f["mean_per_dispatch"] + w["mean_per_dispatch"]),
            "mfma_busy_cycles_sum_per_launch": busy_per_launch, "grbm_gui_active_mean": g["mean_per_dispatch"],
            "MfmaUtil_percent": 100.0 * busy_per_launch / (g["mean_per_dispatch"] * 1024.0) if busy_per_launch else None,
            "avg_launch_us_under_pmc": tot_ns / n / 1e3 if n else None}
+    if stats_txt:
+        ent["rocprof_calls"], ent["rocprof_avg_us"] = kernel_stats(stats_txt, sub)
+        ent["rocprof_source"] = os.path.basename(stats_txt)
     out[key] = ent
 print(json.dumps(out, indent=1))

@@ -16,9 +16,9 @@ try:
          "from pmc_events group by name, counter_name order by 4 desc")
     rows = c.execute(q).fetchall()
     out["per_kernel"] = [{"kernel": r[0][:90], "counter": r[1], "samples": r[2], "sum": r[3], "mean_per_dispatch": r[4],
-                          "sum_duration_ns": r[5]} for r in rows[:60]]
+                          "sum_duration_ns": r[5]} for r in rows[:240]]
     nd = c.execute("select name, count(*), sum(end-start) from kernels group by name order by 3 desc").fetchall()
-    out["dispatches"] = [{"kernel": r[0][:90], "n": r[1], "total_ns": r[2]} for r in nd[:12]]
+    out["dispatches"] = [{"kernel": r[0][:90], "n": r[1], "total_ns": r[2]} for r in nd[:80]]
 except Exception as e:  # schema differs: dump what is there
     out["error"] = repr(e)
     out["sample"] = [list(map(str, r)) for r in c.execute("select * from pmc_events limit 5").fetchall()]

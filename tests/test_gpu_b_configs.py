@@ -153,6 +153,86 @@ def test_config2_bench_workload_one_image_vs_oracle(sd):
     _compare_detections(det.detected, 0, ref, "configs[2] 1000x1000")
 
 
+def test_config2_bench_batch_of_8_vs_oracle_image_by_image(sd):
+    """the TIMED dispatch.  bench.py's step is B = 8 images with 32 injected boxes each (input set 0: image and
+    box seeds g = 0..7) - [8,256,256,256] FPN convs, [256,16,33,256] local-extractor convs, whose conv routing (wide / narrow
+    shape, tile counts, XCD map, pointwise rule) depends on the batch's tile count.  The reference's contract is per-image
+    results (glass_runner.py:93-96): every image of the batch against `O.glass_inference` of that image alone -
+    proposals, detections, character probabilities."""
+    import glass_amd
+    from glass_amd.utils.synth import make_boxes, make_image
+    from oracle import glass_cpu as O
+    cfg = _cfg()
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd)
+    B, R = 8, 32
+    imgs = [make_image(g, 1000, 1000).permute(2, 0, 1).float().contiguous() for g in range(B)]
+    boxes = [make_boxes(g, R, 1000, 1000) for g in range(B)]
+    res = m.inference([{"image": im.cuda()} for im in imgs], do_postprocess=False, override_boxes=[b.cuda() for b in boxes])
+    det = res.batch
+    text = det.text.cpu().numpy()
+    assert text.shape == (B * R, 26, 97)
+    worst = 0.0
+    for g in range(B):
+        ref = O.glass_inference(sd, [imgs[g]], cfg, injected_boxes=[boxes[g]])[0]
+        worst = max(worst, assert_text_prob_close(text[g * R:(g + 1) * R], ref["pred_text_prob"].numpy(),
+                                                  what=f"configs[2] B=8 image {g}, 32 RoIs, text"))
+        _compare_proposals(det, g, ref["proposals"], f"configs[2] B=8 image {g}")
+        _compare_detections(det.detected, g, ref, f"configs[2] B=8 image {g}")
+    print(f"[parity] configs[2] at the bench batch (B=8, R=256): max |dp| over the 8 images = {worst:.3e}")
+
+
+def test_config1_backbone_fpn_batch_of_8_vs_oracle(sd):
+    """configs[1] as quoted - bs = 8 at 1000 x 1000 - every FPN level of every image against the oracle's
+    ResNet-50 + FPN of that image alone."""
+    import glass_amd
+    from glass_amd.utils.synth import make_image
+    from oracle import glass_cpu as O
+    cfg = _cfg()
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd)
+    B = 8
+    imgs = [make_image(g, 1000, 1000).permute(2, 0, 1).float().contiguous() for g in range(B)]
+    il = m.preprocess_image([{"image": im.cuda()} for im in imgs])
+    assert tuple(il.nhwc4.shape) == (B, 1024, 1024, 4)
+    feats = {k: v.permute(0, 3, 1, 2).cpu() for k, v in m.backbone.forward_nhwc(il.nhwc4).items()}
+    worst = {}
+    for g in range(B):
+        x, _ = O.preprocess([imgs[g]], cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+        ref = O.resnet50_fpn(sd, x)
+        for k, r in ref.items():
+            got = feats[k][g:g + 1]
+            assert got.shape == r.shape
+            rel = float((got - r).abs().max()) / max(1.0, float(r.abs().max()))
+            worst[k] = max(worst.get(k, 0.0), rel)
+            assert rel < 1e-3, (g, k, rel)
+    print("[parity] configs[1] B=8 backbone+FPN, max |d| / range per level over the 8 images: " +
+          ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+
+
+def test_local_extractor_at_the_bench_batch_vs_oracle(sd):
+    """the local extractor alone at R = 256 crops (8 images x 32 RoIs: the [256,16,33,256] / [256,32,32,128] /
+    [256,64,64,64] launches of the timed step) against `O.local_extractor`, itself pinned on the reference module
+    (tests/golden/local_extractor.npz; reference local_feature_extraction.py:95-188)."""
+    import glass_amd
+    from oracle import glass_cpu as O
+    cfg = _cfg()
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd)
+    R = 256
+    g = torch.Generator().manual_seed(4242)
+    x = (torch.rand((R, 3, 128, 128), generator=g) * 255.0 - 115.0)
+    x = torch.nn.functional.avg_pool2d(x, 3, 1, 1)                 # crops of a smooth image, mean-subtracted range
+    got = m.roi_heads.hybrid_net.forward(x.cuda()).cpu()
+    worst = 0.0
+    for lo in range(0, R, 64):                                     # the oracle in chunks of 64 crops (memory, not semantics)
+        ref = O.local_extractor(sd, x[lo:lo + 64])
+        assert got[lo:lo + 64].shape == ref.shape == (64, 256, 8, 32)
+        worst = max(worst, float((got[lo:lo + 64] - ref).abs().max()) / max(1.0, float(ref.abs().max())))
+    print(f"[parity] local extractor at R = 256: max |d| / range = {worst:.3e}")
+    assert worst < 1e-3
+
+
 def test_config4_fp16_conv_mode_tracks_the_fp32_path(sd):
     """BASELINE configs[4] asks for an fp16 run: MODEL.CONV_PRECISION fp16 routes every conv / linear through
     glass_conv2d_nhwc_f16 (operands rounded to fp16, fp16 MFMA, fp32 accumulate and storage).  The op itself is exact

@@ -101,7 +101,7 @@ def test_packed_weights_live_and_die_with_the_model():
     import glass_amd
     from glass_amd.ops import native as K
     from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
-    assert not hasattr(K, "_winograd_weights") and "cache" not in K._WINO
+    assert not hasattr(K, "_winograd_weights") and not hasattr(K, "_WINO")
     sd = make_state_dict(1234)
     H, W = 128, 160
     img = make_image(3, H, W).permute(2, 0, 1).float().contiguous().cuda()
@@ -153,3 +153,82 @@ def _conv_weights(obj, depth=0, seen=None):
             yield from _conv_weights(v, depth + 1, seen)
         for v in obj.children():
             yield from _conv_weights(v, depth + 1, seen)
+
+
+def test_two_host_threads_drive_models_of_different_precision():
+    """VERDICT r3 #8 / SURVEY 8b "Threading": kernel routing is a value carried by each model's weights (ops.native.Routing),
+    nothing process-global is read on the launch path.  An fp32 and an fp16s model driven concurrently from two Python threads
+    (each on its own HIP stream) return, every iteration, bit for bit what their serial runs return - with the round-3
+    process-global precision switch the two threads would have launched each other's kernels."""
+    import threading
+
+    import glass_amd
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
+    sd = make_state_dict(1234)
+    H, W = 160, 192
+    img = make_image(11, H, W).permute(2, 0, 1).float().contiguous().cuda()
+    boxes = [(make_boxes(11, 6, H, W) * torch.tensor([1, 1, 0.35, 0.5, 1.0])).cuda()]
+    models = {}
+    for prec in ("fp32", "fp16s"):
+        m = glass_amd.build_model(_cfg(["MODEL.CONV_PRECISION", prec]))
+        m.load_state_dict(sd)
+        assert m.routing.precision == prec and m.backbone.w["stem"][0].routing is m.routing
+        models[prec] = m
+
+    def run(prec):
+        return models[prec].inference([{"image": img}], do_postprocess=False, override_boxes=boxes).batch.text.clone()
+
+    ref = {p: run(p) for p in models}
+    torch.cuda.synchronize()
+    assert not torch.equal(ref["fp32"], ref["fp16s"])
+    ITER = 10
+    got, errs = {p: [] for p in models}, []
+    gate = threading.Barrier(2)
+
+    def worker(prec):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            gate.wait(timeout=60)
+            with torch.cuda.stream(st), torch.no_grad():
+                for _ in range(ITER):
+                    got[prec].append(run(prec))
+                st.synchronize()
+        except BaseException as e:               # noqa: BLE001 - reported by the main thread
+            errs.append((prec, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(p,)) for p in models]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for p in models:
+        assert len(got[p]) == ITER
+        for i, g in enumerate(got[p]):
+            assert torch.equal(g, ref[p]), f"{p} iteration {i}: differs from the serial run"
+    assert K.conv_precision() == "fp32" and K.packs_on_the_fly() >= 0
+
+
+def test_conv_weight_repacks_after_an_in_place_edit():
+    """packs are built once at load; an in-place edit of the raw tensor afterwards (weight surgery, `copy_`) must
+    not leave stale Winograd packs in use."""
+    from glass_amd.ops import native as K
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 32, 32, 64), generator=g).cuda()
+    w1 = (torch.randn((64, 3, 3, 64), generator=g) * 0.05).cuda()
+    w2 = (torch.randn((64, 3, 3, 64), generator=g) * 0.05).cuda()
+    cw = K.prepare_conv_weights(w1.clone())
+    assert cw.packs, "a 64 -> 64 3x3 layer has Winograd forms"
+    y1 = K.conv2d_nhwc(x, cw, None, padding=1, winograd=True)
+    n0 = K.packs_on_the_fly()
+    cw.raw.copy_(w2)
+    y2 = K.conv2d_nhwc(x, cw, None, padding=1, winograd=True)
+    ref2 = K.conv2d_nhwc(x, w2, None, padding=1, winograd=False)
+    assert K.packs_on_the_fly() > n0
+    assert float((y2 - ref2).abs().max()) < 1e-3 and float((y1 - y2).abs().max()) > 1e-2
+    n1 = K.packs_on_the_fly()
+    y3 = K.conv2d_nhwc(x, cw, None, padding=1, winograd=True)          # re-packed once, not on every launch
+    assert K.packs_on_the_fly() == n1 and torch.equal(y3, y2)
