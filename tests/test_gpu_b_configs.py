@@ -233,6 +233,55 @@ def test_local_extractor_at_the_bench_batch_vs_oracle(sd):
     assert worst < 1e-3
 
 
+def test_trained_like_dynamic_range_at_the_bench_batch_vs_oracle(sd):
+    """parity must survive a real checkpoint, not only the O(1) activations of seed 1234.  The checkpoint is
+    re-scaled (`synth.widen_dynamic_range`: res4 / res5 / FPN / local layer3-4 conv gains x1.5-2.5, BN gamma up to x3 with
+    running_var down to 0.1 -> 3x3 layers read inputs of up to 150 ... 420, pyramid levels reach 300 ... 440) and the images are
+    text-like (dark flat background, bright anti-aliased strokes: `synth.make_text_image`), B = 8 at 1000 x 1000 with 32 injected
+    boxes per image - the bench's dispatch, so res2 ... res4, the FPN / RPN convs and the local extractor run the F(4x4,3x3)
+    kernel.  North-star bound (1e-3) on proposal logits, detection scores / boxes and character probabilities, image by image.
+    For the log, the same batch under `f43 = False` (F(2x2,3x3)) and `winograd = False` (direct fp32 MFMA): how much of the delta
+    is the transform and how much is fp32 summation order."""
+    import glass_amd
+    from glass_amd.utils.synth import make_boxes, make_text_image, widen_dynamic_range
+    from oracle import glass_cpu as O
+    cfg = _cfg()
+    wsd = widen_dynamic_range(sd)
+    B, R = 8, 32
+    imgs = [make_text_image(g, 1000, 1000).permute(2, 0, 1).float().contiguous() for g in range(B)]
+    boxes = [make_boxes(100 + g, R, 1000, 1000) for g in range(B)]
+    refs = [O.glass_inference(wsd, [imgs[g]], cfg, injected_boxes=[boxes[g]])[0] for g in range(B)]
+    peak = max(float(r["proposals"][1].abs().max()) for r in refs)
+    print(f"[parity] trained-like checkpoint: oracle proposal logits up to {peak:.1f}")
+    inputs = [{"image": im.cuda()} for im in imgs]
+    dboxes = [b.cuda() for b in boxes]
+    for label, switches in (("default routing (F(4x4,3x3) where it pays)", {}), ("f43 off (F(2x2,3x3))", {"f43": False}),
+                            ("winograd off (direct fp32 MFMA)", {"winograd": False})):
+        m = glass_amd.build_model(cfg)
+        for k, v in switches.items():
+            setattr(m.routing, k, v)                     # this model's own Routing; stamped on its weights at load
+        m.load_state_dict(wsd)
+        det = m.inference(inputs, do_postprocess=False, override_boxes=dboxes).batch
+        text = det.text.cpu().numpy()
+        pb, pl, pc = det.proposals
+        dl = dp = 0.0
+        for g in range(B):
+            c = int(pc[g])
+            if c == len(refs[g]["proposals"][0]):
+                dl = max(dl, maxdiff(np.sort(pl[g, :c].cpu().numpy()), np.sort(refs[g]["proposals"][1].numpy())))
+            q = refs[g]["pred_text_prob"].numpy()
+            live = q.sum(-1) > 0
+            dp = max(dp, float(np.abs(text[g * R:(g + 1) * R] - q)[live][:, None].max()) if live.any() else 0.0)
+        print(f"[parity] trained-like checkpoint, {label}: max |dlogit| (sorted proposals) = {dl:.3e}, raw max |dp| text = {dp:.3e}")
+        if switches:
+            continue
+        for g in range(B):
+            assert_text_prob_close(text[g * R:(g + 1) * R], refs[g]["pred_text_prob"].numpy(),
+                                   what=f"trained-like checkpoint, image {g}, text")
+            _compare_proposals(det, g, refs[g]["proposals"], f"trained-like checkpoint, image {g}")
+            _compare_detections(det.detected, g, refs[g], f"trained-like checkpoint, image {g}")
+
+
 def test_config4_fp16_conv_mode_tracks_the_fp32_path(sd):
     """BASELINE configs[4] asks for an fp16 run: MODEL.CONV_PRECISION fp16 routes every conv / linear through
     glass_conv2d_nhwc_f16 (operands rounded to fp16, fp16 MFMA, fp32 accumulate and storage).  The op itself is exact
