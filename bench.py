@@ -103,7 +103,11 @@ class ConvMeter:
             cin_real = 3 if cin == 4 else cin           # NHWC4-padded RGB inputs
             algo = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * kh * kw_ * cin_real
             path = self.K.last_conv_path()
-            if path == "winograd43":                    # F(4x4,3x3): 36 MACs per (ceil(H/4) x ceil(W/4)) tile, channel pair
+            if path == "winograd43r":                   # width 4 k + 1: F(4x4) on the k full tile columns + the last column direct (3 x 2 taps)
+                ex = 2.0 * y.shape[0] * ((y.shape[1] + 3) // 4) * (y.shape[2] // 4) * 36 * cout * cin + \
+                    2.0 * y.shape[0] * y.shape[1] * cout * 6 * cin
+                path = "winograd43"
+            elif path == "winograd43":                  # F(4x4,3x3): 36 MACs per (ceil(H/4) x ceil(W/4)) tile, channel pair
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 3) // 4) * ((y.shape[2] + 3) // 4) * 36 * cout * cin
             elif path.startswith("winograd"):           # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2) * 16 * cout * cin
@@ -113,10 +117,29 @@ class ConvMeter:
                                    kw.get("residual") is not None, algo, ex, e0, e1))
             return y
         self.K.conv2d_nhwc = wrapped
+        # the two fused stems (conv + conv/pool in one kernel) are convolution work too: metered as family "fused_stem" with the
+        # direct-convolution FLOP of the convs they contain (max-pools are 0 FLOP)
+        self.orig_bstem, self.orig_lstem = self.K.backbone_stem_fused, self.K.local_stem_fused
+
+        def timed(fn, flops_of, tag):
+            def run(x, *a, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                y = fn(x, *a, **kw)
+                e1.record()
+                fl = flops_of(x)
+                self.steps[-1].append(("fused_stem", tuple(x.shape), tag, 1, False, fl, fl, e0, e1))
+                return y
+            return run
+        self.K.backbone_stem_fused = timed(self.orig_bstem, lambda x: 2.0 * x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2) * 64 * 49 * 3,
+                                           (64, 7, 7))
+        self.K.local_stem_fused = timed(self.orig_lstem, lambda x: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 9 * (16 * 3 + 32 * 16),
+                                        (32, 3, 3))
         return self
 
     def __exit__(self, *a):
         self.K.conv2d_nhwc = self.orig
+        self.K.backbone_stem_fused, self.K.local_stem_fused = self.orig_bstem, self.orig_lstem
 
     def _launches(self):
         """[(family, x shape, w dims, stride, +res, algo, exec, median ms)] in launch order"""
@@ -138,7 +161,7 @@ class ConvMeter:
 
     def summary(self):
         out = {k: {"launches": 0, "ms": 0.0, "algo_flops": 0.0, "exec_flops": 0.0}
-               for k in ("winograd43", "winograd128", "winograd", "pointwise", "direct", "direct_fp16", "packed_fp16")}
+               for k in ("winograd43", "winograd128", "winograd", "pointwise", "direct", "direct_fp16", "packed_fp16", "fused_stem")}
         for p, _xs, _ws, _st, _res, algo, ex, ms in self._launches():
             f = out[p]
             f["launches"] += 1
@@ -465,9 +488,10 @@ def main():
                  "pointwise": "conv1x1_pw_f32 (fp32 MFMA 16x16x4 weight-streaming 1x1 GEMM)",
                  "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
                  "direct_fp16": "conv_igemm_f32<..., HALF> (fp16 MFMA implicit-GEMM conv/linear, fp32 accumulate)",
-                 "packed_fp16": "conv_h16_kernel (fp16 MFMA 16x16x32 weight-streaming implicit-GEMM conv on fp16 tensors, fp32 accumulate)"}
+                 "packed_fp16": "conv_h16_kernel (fp16 MFMA 16x16x32 weight-streaming implicit-GEMM conv on fp16 tensors, fp32 accumulate)",
+                 "fused_stem": "backbone_stem_fused_kernel + local_stem_fused_kernel (conv + ReLU + max-pool fused stems, fp32 MFMA 32x32x2)"}
         PKEY = {"winograd43": "conv3x3_wino43_f32", "winograd128": "conv3x3_wino128_f32", "winograd": "conv3x3_wino_f32", "pointwise": "conv1x1_pw_f32", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
-                "direct_fp16": "conv_igemm_f16", "packed_fp16": "conv_h16_kernel"}
+                "direct_fp16": "conv_igemm_f16", "packed_fp16": "conv_h16_kernel", "fused_stem": "backbone_stem_fused_kernel"}
         PEAK = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else FP16_MFMA_PEAK_TFLOPS
         dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time
         # PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate
@@ -475,7 +499,9 @@ def main():
         pmc_all, pmc_file, pmc_note = {}, None, "no PMC summary under profiles/"
         from glass_amd._lib import source_sha16
         import glob
-        for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_summary.json")), reverse=True):
+        # fp32: r*_pmc_conv_summary.json; the fp16-storage mode has its own passes (scripts/collect_profiles.sh step 3b)
+        pmc_glob = "r*_pmc_conv_summary.json" if args.precision == "fp32" else f"r*_pmc_{args.precision}_summary.json"
+        for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", pmc_glob)), reverse=True):
             with open(cand) as f:
                 js = json.load(f)
             if js.get("lib_source_sha16") == source_sha16():

@@ -415,8 +415,27 @@ extern "C" int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, 
   return GLASS_OK;
 }
 
+static int wino43_launch(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias, const float* residual,
+                         float* y, glass_stream_t stream, bool body_only);
+
 extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
                                              const float* bias, const float* residual, float* y, glass_stream_t stream) {
+  return wino43_launch(d, x, u_packed, bias, residual, y, stream, false);
+}
+
+// Only the FULL 4-column tile columns: output columns [0, 4 * (W / 4)) of every row.  A map whose width is 4 k + 1 (the local
+// extractor's 16 x 33 maps, reference local_feature_extraction.py:124 `MaxPool2d(2, (2, 1), (0, 1))`) otherwise pays a whole
+// tile column - 36 multiplies per tile, exactly the direct convolution of its 16 outputs - for ONE pixel column, and its
+// tile count (36 per map instead of 32) turns 4 rounds of workgroups into 4.5; the caller computes the last column with
+// glass_conv2d_nhwc on the 2-column strip (KH = 3, KW = 1 over channels = (kw, cin); ops/native.py conv2d_nhwc).
+extern "C" int glass_conv3x3_winograd43_body_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
+                                                  const float* bias, const float* residual, float* y, glass_stream_t stream) {
+  GLASS_CHECK_ARG(d && d->W >= 4, "glass_conv3x3_winograd43_body_nhwc: needs W >= 4");
+  return wino43_launch(d, x, u_packed, bias, residual, y, stream, true);
+}
+
+static int wino43_launch(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias, const float* residual,
+                         float* y, glass_stream_t stream, bool body_only) {
   GLASS_CHECK_ARG(d && x && u_packed && y, "glass_conv3x3_winograd43_nhwc: null pointer");
   GLASS_CHECK_ARG(glass_winograd43_supported(d),
                   "glass_conv3x3_winograd43_nhwc: needs 3x3/stride 1/pad 1, Cin%%16==0, Cout%%64==0, unit channel stride, "
@@ -430,7 +449,7 @@ extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const flo
   WinoParams p;
   p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y; p.dbg = nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
-  p.TH = (d->H + 3) / 4; p.TW = (d->W + 3) / 4;
+  p.TH = (d->H + 3) / 4; p.TW = body_only ? d->W / 4 : (d->W + 3) / 4;      // (input / output bounds still use the true W)
   const long nt = (long)d->N * p.TH * p.TW;
   GLASS_CHECK_ARG(nt < 0x7fffffffL, "glass_conv3x3_winograd43_nhwc: too many tiles");
   p.ntiles = (int)nt;

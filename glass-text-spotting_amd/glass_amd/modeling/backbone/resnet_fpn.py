@@ -75,8 +75,12 @@ class ResNetFPN(InferenceModule):
         """x: [N,Hp,Wp,4] normalised NHWC4 batch -> {p2..p6} NHWC tensors."""
         w = self.w
         # entry of the conv chain: in 'fp16s' mode the stem writes fp16 and every later conv / pool follows its input's dtype
-        x = K.conv2d_nhwc(x, *w["stem"], stride=2, padding=3, relu=1, out_dtype=K.act_dtype(w["stem"][0]))
-        x = K.maxpool2d_nhwc(x, 3, 2, 1)
+        if w["stem"][1] is not None and K.backbone_stem_supported(x, w["stem"][0]):
+            # conv 7x7 s2 + BN + ReLU + max-pool 3x3 s2 in one kernel (csrc/backbone_stem.hip): the [N,H/2,W/2,64] map stays on the CU
+            x = K.backbone_stem_fused(x, *w["stem"])
+        else:
+            x = K.conv2d_nhwc(x, *w["stem"], stride=2, padding=3, relu=1, out_dtype=K.act_dtype(w["stem"][0]))
+            x = K.maxpool2d_nhwc(x, 3, 2, 1)
         feats = {}
         for sname, nblk in _STAGES:
             for b in range(nblk):

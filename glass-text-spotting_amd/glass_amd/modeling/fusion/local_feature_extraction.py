@@ -45,14 +45,17 @@ class ResNetFeatureExtractor(InferenceModule):
         w["conv0_1"] = fold_conv(sd, p + "conv0_1", p + "bn0_1", device)
         w["conv0_2"] = fold_conv(sd, p + "conv0_2", p + "bn0_2", device)
         for li, nblk in _LAYERS:
+            # layer3 / layer4 (and conv3) run behind maxpool3 = MaxPool2d(2, (2, 1), (0, 1)) (reference :124): width W/4 + 1,
+            # i.e. 33 for the 128-pixel crops of every config - a 4 k + 1 map: these layers carry the last-column strip weights
+            rg = li >= 3
             for b in range(nblk):
                 q = f"{p}layer{li}.{b}."
-                w[f"l{li}.{b}.conv1"] = fold_conv(sd, q + "conv1", q + "bn1", device)
-                w[f"l{li}.{b}.conv2"] = fold_conv(sd, q + "conv2", q + "bn2", device)
+                w[f"l{li}.{b}.conv1"] = fold_conv(sd, q + "conv1", q + "bn1", device, ragged=rg)
+                w[f"l{li}.{b}.conv2"] = fold_conv(sd, q + "conv2", q + "bn2", device, ragged=rg)
                 if (q + "downsample.0.weight") in sd:
                     w[f"l{li}.{b}.down"] = fold_conv(sd, q + "downsample.0", q + "downsample.1", device)
             if li < 4:
-                w[f"conv{li}"] = fold_conv(sd, f"{p}conv{li}", f"{p}bn{li}", device)
+                w[f"conv{li}"] = fold_conv(sd, f"{p}conv{li}", f"{p}bn{li}", device, ragged=rg)
         w["conv4_1"] = fold_conv(sd, p + "conv4_1", p + "bn4_1", device)
         self.w = w
 

@@ -97,11 +97,15 @@ class Routing:
       f43         ... F(4x4,3x3) where it pays (GLASS_WINOGRAD43=0: F(2x2,3x3) only)
       pw          the weight-streaming 1x1 kernel: True (the end-to-end rule), False, or "all" (every supported layer)
       h16         fp16 modes: the packed-weight fp16-MFMA kernel (GLASS_CONV_H16=0: fp32 template with fp16 operands)
-      local_stem  the fused conv0_1 + conv0_2 + maxpool kernel of the local extractor (GLASS_LOCAL_STEM=0: three launches)"""
-    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem")
+      local_stem  the fused conv0_1 + conv0_2 + maxpool kernel of the local extractor (GLASS_LOCAL_STEM=0: three launches)
+      stem        the fused 7x7 conv + ReLU + max-pool kernel of the ResNet stem (GLASS_BACKBONE_STEM=0: two launches)
+      ragged      maps of width 4 k + 1 on the F(4x4) kernel: full tile columns there + the last pixel column as a strip
+                  convolution (GLASS_W43_RAGGED=0: a whole extra tile column, as in rounds 2-3)"""
+    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged")
 
     def __init__(self, precision: Optional[str] = None, winograd: Optional[bool] = None, f43: Optional[bool] = None, pw=None,
-                 h16: Optional[bool] = None, local_stem: Optional[bool] = None):
+                 h16: Optional[bool] = None, local_stem: Optional[bool] = None, stem: Optional[bool] = None,
+                 ragged: Optional[bool] = None):
         e = os.environ.get
         self.precision = precision or e("GLASS_CONV_PRECISION", "fp32")
         if self.precision not in _PRECISIONS:
@@ -111,6 +115,8 @@ class Routing:
         self.pw = {"0": False, "all": "all"}.get(e("GLASS_POINTWISE", "1"), True) if pw is None else (pw if pw == "all" else bool(pw))
         self.h16 = (e("GLASS_CONV_H16", "1") != "0") if h16 is None else bool(h16)
         self.local_stem = (e("GLASS_LOCAL_STEM", "1") != "0") if local_stem is None else bool(local_stem)
+        self.stem = (e("GLASS_BACKBONE_STEM", "1") != "0") if stem is None else bool(stem)
+        self.ragged = (e("GLASS_W43_RAGGED", "1") != "0") if ragged is None else bool(ragged)
 
     def replace(self, **kw) -> "Routing":
         r = Routing.__new__(Routing)
@@ -169,7 +175,7 @@ def act_dtype(w=None) -> torch.dtype:
 
 
 def last_conv_path() -> str:
-    """'pointwise' (conv1x1_pw_f32), 'winograd43' (conv3x3_wino43_f32), 'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct', 'direct_fp16' (fp32 template, fp16 operands) or 'packed_fp16' (conv_h16_kernel): which kernel
+    """'pointwise' (conv1x1_pw_f32), 'winograd43' (conv3x3_wino43_f32; 'winograd43r': its full tile columns + the last pixel column as a strip convolution), 'fused_stem', 'winograd128' / 'winograd' (conv3x3_wino128_f32 / conv3x3_wino_f32), 'direct', 'direct_fp16' (fp32 template, fp16 operands) or 'packed_fp16' (conv_h16_kernel): which kernel
     the most recent conv2d_nhwc call OF THIS HOST THREAD launched (bench/profiling aid)."""
     return getattr(_TLS, "last_path", "direct")
 
@@ -215,6 +221,10 @@ def winograd_pack(w: torch.Tensor, f43=False) -> torch.Tensor:
     _f32c(w, "w")
     Cout, KH, KW, Cin = w.shape
     L = lib()
+    if f43 == "col1":
+        # the last-pixel-column strip of a 3x3 / pad-1 layer: output column W-1 reads input columns W-2, W-1 (W is padding),
+        # i.e. taps kw = 0, 1 -> a KH = 3, KW = 1 convolution over channels (kw, cin): [Cout,3,1,2*Cin]
+        return w[:, :, 0:2, :].reshape(Cout, 3, 1, 2 * Cin).contiguous()
     if f43 == "h16":
         u = torch.empty((int(L.glass_conv_h16_weight_halves(Cout, KH, KW, Cin)),), dtype=torch.float16, device=w.device)
         check(L.glass_conv_h16_pack_weights(c_void_p(_dev(w, "w")), Cout, KH, KW, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())),
@@ -231,10 +241,11 @@ def winograd_pack(w: torch.Tensor, f43=False) -> torch.Tensor:
     return u
 
 
-def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int) -> bool:
+def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int, body: bool = False) -> bool:
     """F(4x4,3x3) pays when the 4x4 tiling does not waste much of the map (H, W rounded up to multiples of 4 vs 2)
-    and the grid still fills the chip (16 tiles x 128 channels per workgroup; 32 x 64 for the narrow shape)."""
-    t4 = ((H + 3) // 4) * ((W + 3) // 4)
+    and the grid still fills the chip (16 tiles x 128 channels per workgroup; 32 x 64 for the narrow shape).  `body`: only the
+    full tile columns run on this kernel (width 4 k + 1: the last column is a strip convolution)."""
+    t4 = ((H + 3) // 4) * (W // 4 if body else (W + 3) // 4)
     waste = (t4 * 16.0) / (((H + 1) // 2) * ((W + 1) // 2) * 4.0)
     wide = Cout % 128 == 0 and Cin % 32 == 0
     blocks = ((N * t4 + 15) // 16) * (Cout // 128) if wide else ((N * t4 + 31) // 32) * (Cout // 64)
@@ -296,12 +307,12 @@ def _probe_desc(Cout: int, KH: int, KW: int, Cin: int) -> ConvDesc:
     return ConvDesc(1, 16, 16, Cin, Cout, KH, KW, 1, 1, ph, pw, 16 + 2 * ph - KH + 1, 16 + 2 * pw - KW + 1, Cin, Cout, 0, 1, 0, 0, 0)
 
 
-def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str, stride=1, hint_hw: Optional[Tuple[int, int]] = None) -> list:
+def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str, stride=1, ragged: bool = False) -> list:
     """which packed forms a [Cout,KH,KW,Cin] weight can be asked for under `precision` (the routing of conv2d_nhwc);
     "all": every form the layer supports (micro-benchmarks that force kernels across precisions).  `stride` != 1 rules the
     Winograd forms out (stride-2 3x3 layers were carrying 52/9 of their size in packs no launch could take)."""
     if precision == "all":
-        return pack_kinds(Cout, KH, KW, Cin, "fp32", stride) + pack_kinds(Cout, KH, KW, Cin, "fp16", stride)
+        return pack_kinds(Cout, KH, KW, Cin, "fp32", stride, ragged) + pack_kinds(Cout, KH, KW, Cin, "fp16", stride)
     L, d = lib(), _probe_desc(Cout, KH, KW, Cin)
     kinds = []
     if precision == "fp32":
@@ -310,6 +321,8 @@ def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str, stride=1, 
                 kinds.append(False)
             if L.glass_winograd43_supported(ctypes.byref(d)):
                 kinds.append(True)
+                if ragged and (2 * Cin) % 32 == 0:
+                    kinds.append("col1")     # the layer meets maps of width 4 k + 1 (caller's hint): strip weights of the last column
         if KH == 1 and KW == 1 and L.glass_pointwise_supported(ctypes.byref(d)):
             kinds.append("pw")
     elif Cin % 64 == 0 and L.glass_conv_h16_supported(ctypes.byref(d), 1):
@@ -317,10 +330,11 @@ def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str, stride=1, 
     return kinds
 
 
-def prepare_conv_weights(w: torch.Tensor, precision: Optional[str] = None, stride=1) -> ConvWeight:
+def prepare_conv_weights(w: torch.Tensor, precision: Optional[str] = None, stride=1, ragged: bool = False) -> ConvWeight:
     """w [Cout,KH,KW,Cin] (or [Nout,K] for a linear layer) fp32 on the device -> ConvWeight with every packed form its layer
     can be routed to under `precision` (default: the enclosing packing_for(), else the raw-tensor default precision).
-    `stride`: the layer's stride when the caller knows it (a stride-2 3x3 layer needs no Winograd form).  Load-time plumbing:
+    `stride`: the layer's stride when the caller knows it (a stride-2 3x3 layer needs no Winograd form); `ragged`: the layer
+    runs on maps of width 4 k + 1 (the local extractor's 16 x 33 maps) and wants the last-column strip weights.  Load-time plumbing:
     ~10 pack kernels per MB of weights, once per model."""
     if isinstance(w, ConvWeight):
         return w
@@ -331,7 +345,7 @@ def prepare_conv_weights(w: torch.Tensor, precision: Optional[str] = None, strid
     precision = precision or (load.precision if load is not None else _DEFAULT.precision)
     Cout, KH, KW, Cin = w.shape
     if w.is_cuda:
-        for kind in pack_kinds(Cout, KH, KW, Cin, precision, stride):
+        for kind in pack_kinds(Cout, KH, KW, Cin, precision, stride, ragged):
             cw.packs[kind] = winograd_pack(w, kind)
         if cw.packs and load is None:
             torch.cuda.current_stream().synchronize()      # other streams (pipelined steps) may launch with it next
@@ -453,8 +467,19 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
         # the Winograd kernel runs one 64-tile x 64-channel workgroup per CU: below ~96 workgroups (FPN p6, batch-2 res5)
         # the direct kernel's smaller tiles fill the chip better (measured 0.68-0.82x vs 1.15x at 128 workgroups)
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
-    f43 = winograd == "f43" or (winograd is None and rt.f43 and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin))
+    ragged = (rt.ragged and KH == 3 and KW == 3 and W % 4 == 1 and W >= 5 and (2 * Cin) % 32 == 0 and out_cstride == 1 and
+              res_mode in (0, 1) and x.numel() > 0)
+    f43 = winograd == "f43" or (winograd is None and rt.f43 and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin, ragged))
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
+        if ragged:
+            # width 4 k + 1 (the local extractor's 16 x 33 maps): the F(4x4) kernel on the k full tile columns - 32 instead of
+            # 36 tiles per 16 x 33 map, and e.g. 1024 instead of 1152 workgroups = 4 instead of 4.5 rounds on 256 CUs - and
+            # the last pixel column as a KH = 3, KW = 1 convolution over the last two input columns seen as 2*Cin channels
+            # (x, y and the residual re-viewed as [N,H,1,W*ld] rows with a channel offset; no copy)
+            launch("glass_conv3x3_winograd43_body_nhwc", "winograd43", x, _packed(w, wt, True))
+            _last_column_strip(x, _packed(w, wt, "col1"), bias, residual, out, d, out_coff)
+            _TLS.last_path = "winograd43r"          # (bench / profiling: F(4x4) body + last-column strip)
+            return out
         return launch("glass_conv3x3_winograd43_nhwc", "winograd43", x, _packed(w, wt, True))
     if winograd == "f43":
         raise GlassLibraryError("winograd='f43' but glass_winograd43_supported() rejects this layer")
@@ -464,6 +489,23 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     if winograd:
         raise GlassLibraryError("winograd=True but glass_winograd_supported() rejects this layer")
     return launch("glass_conv2d_nhwc", "direct", x, wt)
+
+
+def _last_column_strip(x: torch.Tensor, wcol: torch.Tensor, bias, residual, out: torch.Tensor, d: ConvDesc, out_coff: int) -> None:
+    """output column W-1 of the 3x3 / pad-1 layer `d`: glass_conv2d_nhwc with KH 3, KW 1, pad (1, 0) on rows re-viewed as ONE
+    pixel of W*ld channels - input channels [(W-2)*ldx, W*ldx) = the last two columns (needs ldx == Cin: dense rows), output
+    channels [(W-1)*ldy + y_coff, ...) and the residual likewise.  Same stream, after the body launch."""
+    N, H, W, Cin, Cout = d.N, d.H, d.W, d.Cin, d.Cout
+    if d.ldx != Cin:
+        raise GlassLibraryError("ragged-width split needs a dense input (ldx == Cin)")
+    ds = ConvDesc(N, H, 1, 2 * Cin, Cout, 3, 1, 1, 1, 1, 0, H, 1, W * d.ldx, W * d.ldy, (W - 1) * d.ldy + out_coff, 1, d.relu,
+                  d.res_mode, W * d.ldr if d.res_mode else 0)
+    isz = x.element_size()
+    xp = _dev(x, "x") + (W - 2) * d.ldx * isz
+    rp = (_dev(residual, "residual") + (W - 1) * d.ldr * residual.element_size()) if (residual is not None and d.res_mode) else None
+    check(lib().glass_conv2d_nhwc(ctypes.byref(ds), c_void_p(xp), c_void_p(_dev(wcol, "w")),
+                                  c_void_p(_dev(bias, "bias") if bias is not None else None), c_void_p(rp), c_void_p(_dev(out, "out")),
+                                  c_void_p(stream_handle())), "glass_conv2d_nhwc(last column)")
 
 
 def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, relu: int = 0,
@@ -501,6 +543,28 @@ def local_stem_fused(x: torch.Tensor, w1, b1: torch.Tensor, w2, b2: torch.Tensor
     fn = lib().glass_local_stem_fused_h16 if h16 else lib().glass_local_stem_fused
     check(fn(c_void_p(_dev(x)), c_void_p(_dev(w1)), c_void_p(_dev(b1)), c_void_p(_dev(w2)), c_void_p(_dev(b2)), c_void_p(_dev(y)),
              R, H, W, c_void_p(stream_handle())), "glass_local_stem_fused")
+    return y
+
+
+def backbone_stem_supported(x: torch.Tensor, w) -> bool:
+    """the fused 7x7 conv + ReLU + 3x3 max-pool kernel takes fp32 NHWC4 batches with H, W multiples of 4 under an fp32 routing"""
+    rt = routing_of(w)
+    wt = _raw(w)
+    return (rt.precision == "fp32" and rt.stem and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] == 4 and
+            tuple(wt.shape) == (64, 7, 7, 4) and x.shape[0] > 0 and
+            bool(lib().glass_backbone_stem_supported(int(x.shape[1]), int(x.shape[2]))))
+
+
+def backbone_stem_fused(x: torch.Tensor, w, bias: torch.Tensor) -> torch.Tensor:
+    """x [N,H,W,4] -> maxpool3x3s2p1(relu(conv7x7s2p3(x, w) + bias)) [N,H/4,W/4,64] in one kernel (csrc/backbone_stem.hip)"""
+    wt = _raw(w)
+    for t, n in ((x, "x"), (wt, "w"), (bias, "bias")):
+        _f32c(t, n)
+    N, H, W, _ = x.shape
+    y = torch.empty((N, H // 4, W // 4, 64), dtype=torch.float32, device=x.device)
+    check(lib().glass_backbone_stem_fused(c_void_p(_dev(x)), c_void_p(_dev(wt)), c_void_p(_dev(bias)), c_void_p(_dev(y)), N, H, W,
+                                          c_void_p(stream_handle())), "glass_backbone_stem_fused")
+    _TLS.last_path = "fused_stem"
     return y
 
 

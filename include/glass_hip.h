@@ -134,6 +134,13 @@ size_t glass_winograd43_weight_floats(int Cout, int Cin);
 int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, float* u_packed, glass_stream_t stream);
 int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                   const float* residual, float* y, glass_stream_t stream);
+/* the same kernel restricted to the FULL tile columns: writes output columns [0, 4 * (W / 4)) only (W >= 4).  For maps of
+ * width 4 k + 1 - the local extractor's 16 x 33 maps (reference glass/modeling/fusion/local_feature_extraction.py:124,
+ * MaxPool2d(2, (2, 1), (0, 1)); 17 launches per step) - the ragged tile column would cost a full column of tiles for one
+ * pixel column; the caller computes that column with glass_conv2d_nhwc on the last two input columns (KH 3, KW 1 over
+ * channels = (kw, cin), see glass_amd/ops/native.py).  Same descriptor (the TRUE H, W), epilogue and errors.          */
+int glass_conv3x3_winograd43_body_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
+                                       const float* residual, float* y, glass_stream_t stream);
 
 /* 1x1 convolution as a weight-streaming GEMM (csrc/pointwise.hip): the bottleneck / lateral / shortcut 1x1 layers with
  * Cin % 32 == 0 and Cout % 128 == 0, any square stride, pad 0.  Same descriptor, epilogue semantics (bias, ReLU before /
@@ -161,6 +168,15 @@ int glass_local_stem_fused(const float* x, const float* w1, const float* b1, con
  * fp16 - the results of glass_conv2d_nhwc_h16 x 2 + glass_maxpool2d_nhwc_h16 up to fp32 summation order.            */
 int glass_local_stem_fused_h16(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
                                int R, int H, int W, glass_stream_t stream);
+
+/* Fused ResNet stem (detectron2 BasicStem, [d2-recall], as restated in oracle/glass_cpu.py resnet50_fpn):
+ * conv 7x7 stride 2 pad 3 (3 -> 64, BatchNorm folded into w / bias) + ReLU + max_pool2d(3, 2, 1) in ONE kernel
+ * (csrc/backbone_stem.hip) - the [N,H/2,W/2,64] map between them stays on the CU.  x [N,H,W,4] NHWC4 (4th channel ignored),
+ * w [64][7][7][4], bias [64], y [N,H/4,W/4,64]; fp32.  The results of glass_conv2d_nhwc + glass_maxpool2d_nhwc up to fp32
+ * summation order.  glass_backbone_stem_supported: H and W positive multiples of 4 - otherwise callers use the two entries. */
+int glass_backbone_stem_supported(int H, int W);
+int glass_backbone_stem_fused(const float* x, const float* w, const float* bias, float* y, int N, int H, int W,
+                              glass_stream_t stream);
 
 /* max pooling NHWC (d2 stem max_pool2d k3 s2 p1; local extractor maxpool1..3,
  * glass/modeling/fusion/local_feature_extraction.py:112,118,124). Padding acts as -inf. */

@@ -112,6 +112,92 @@ WINO43_CASES = [
 ]
 
 
+@pytest.mark.parametrize("R,H,W,Cin,Cout,relu,use_res,strided", [
+    (64, 16, 33, 256, 256, 1, True, None),        # the local extractor's layer3 / layer4 BasicBlock conv2 (+ residual, ReLU after)
+    (40, 16, 33, 128, 256, 1, False, None),       # layer3.0 conv1 (128 -> 256)
+    (24, 16, 33, 256, 256, 0, False, (512, 256)), # into a wider buffer at a channel offset
+    (6, 12, 5, 64, 64, 2, True, None),            # narrow shape, one full tile column + the strip, ReLU before the residual
+    (3, 7, 9, 16, 128, 1, True, None),            # Cin = 16 (strip K = 3 x 32)
+])
+def test_winograd43_ragged_width_split_vs_torch(R, H, W, Cin, Cout, relu, use_res, strided):
+    """Maps of width 4 k + 1 (reference local_feature_extraction.py:124: MaxPool2d(2, (2, 1), (0, 1)) -> 16 x 33): the F(4x4,3x3)
+    kernel on the full tile columns (glass_conv3x3_winograd43_body_nhwc) + the last pixel column as glass_conv2d_nhwc over the
+    last two input columns, against torch CPU fp64 - every column, the last one in particular - with the layer's weights
+    prepared ONCE (the load-time 'col1' pack: no launch packs anything)."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    x = _rand((R, Cin, H, W), 21)
+    w = _rand((Cout, Cin, 3, 3), 22, (2.0 / (Cin * 9)) ** 0.5)
+    b = _rand((Cout,), 23, 0.1)
+    res = _rand((R, Cout, H, W), 24) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu == 2:
+        ref = F.relu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    if relu == 1:
+        ref = F.relu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    cw = K.prepare_conv_weights(w.permute(0, 2, 3, 1).contiguous().to(dev), ragged=True)
+    assert "col1" in cw.packs and True in cw.packs
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
+    kw = dict(padding=1, relu=relu, residual=rd, res_mode=1 if rd is not None else 0)
+    n0 = K.packs_on_the_fly()
+    if strided is None:
+        y = K.conv2d_nhwc(xd, cw, b.to(dev), winograd="f43", **kw)
+    else:
+        ld, coff = strided
+        buf = torch.full((R, H, W, ld), 7.0, device=dev)
+        K.conv2d_nhwc(xd, cw, b.to(dev), winograd="f43", out=buf, out_coff=coff, **kw)
+        torch.cuda.synchronize()
+        assert float((buf[..., :coff] - 7.0).abs().max()) == 0.0 and (coff + Cout == ld or float((buf[..., coff + Cout:] - 7.0).abs().max()) == 0.0)
+        y = buf[..., coff:coff + Cout]
+    assert K.last_conv_path() == "winograd43r" and K.packs_on_the_fly() == n0
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    scale = float(ref.abs().max())
+    e_body = float((got[..., :W - 1] - ref[..., :W - 1]).abs().max()) / scale
+    e_last = float((got[..., W - 1] - ref[..., W - 1]).abs().max()) / scale
+    print(f"F(4x4,3x3) ragged split [{R},{H},{W},{Cin}]->{Cout}: max err / range = {e_body:.2e} (tile columns), {e_last:.2e} (last column, direct)")
+    assert e_body <= 2e-5 and e_last <= 2e-5
+
+
+def test_backbone_stem_fused_matches_the_two_launches_and_torch():
+    """glass_backbone_stem_fused (conv 7x7 s2 p3 + bias + ReLU + max_pool2d(3, 2, 1) in one kernel, csrc/backbone_stem.hip) against
+    the two launches it replaces and, on the smaller shapes, against torch CPU fp64 - shapes that cross the kernel's seams: more
+    than one 256-column block (left halo column on the vector ALU), bands shorter than the image, a ragged last band, W / 2 not
+    a multiple of 32."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    w = _rand((64, 3, 7, 7), 31, (2.0 / 147) ** 0.5 / 32)
+    b = _rand((64,), 32, 0.1)
+    w4 = torch.zeros((64, 7, 7, 4))
+    w4[..., :3] = w.permute(0, 2, 3, 1)
+    wd, bd = w4.contiguous().to(dev), b.to(dev)
+    off = K.default_routing().replace(stem=False)
+    for (N, H, W) in ((2, 64, 96), (1, 36, 40), (3, 72, 1040), (1, 264, 1100), (8, 128, 544), (200, 36, 32)):   # last: 8-row bands, ragged last band (Hp = 9)
+        x = _rand((N, 3, H, W), 33 + H, 60.0)
+        x4 = torch.zeros((N, H, W, 4))
+        x4[..., :3] = x.permute(0, 2, 3, 1)
+        xd = x4.contiguous().to(dev)
+        assert K.backbone_stem_supported(xd, wd)
+        y = K.backbone_stem_fused(xd, wd, bd)
+        u = K.maxpool2d_nhwc(K.conv2d_nhwc(xd, wd, bd, stride=2, padding=3, relu=1, routing=off), 3, 2, 1)
+        torch.cuda.synchronize()
+        assert y.shape == u.shape == (N, H // 4, W // 4, 64)
+        scale = float(u.abs().max())
+        d = float((y - u).abs().max()) / scale
+        msg = f"fused stem [{N},{H},{W}]: max |fused - two launches| / range = {d:.2e}"
+        assert d <= 2e-6, msg
+        if H * W <= 72 * 1040:
+            ref = F.max_pool2d(F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=3)), 3, 2, 1)
+            e = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max()) / float(ref.abs().max())
+            msg += f", vs torch fp64 {e:.2e}"
+            assert e <= 2e-6, msg
+        print(msg)
+    # not a multiple of 4: the two-launch path stays
+    assert not K.backbone_stem_supported(torch.zeros((1, 34, 40, 4), device=dev), wd)
+
+
 @pytest.mark.parametrize("case", WINO43_CASES)
 def test_winograd43_matches_direct_and_torch(case):
     """glass_conv3x3_winograd43_nhwc (F(4x4,3x3), points 0, 1, -1, 1/2, -2, inf) vs torch CPU fp64 and vs the direct kernel.
@@ -136,8 +222,15 @@ def test_winograd43_matches_direct_and_torch(case):
     kw = dict(padding=1, relu=relu, residual=rd, res_mode=1 if rd is not None else 0)
     if strided is None:
         yw = K.conv2d_nhwc(xd, wd, b.to(dev), winograd="f43", **kw)
-        assert K.last_conv_path() == "winograd43"
+        # width 4 k + 1: the kernel runs the k full tile columns, the last pixel column is a strip convolution ("winograd43r")
+        split = W % 4 == 1 and W >= 5 and (2 * Cin) % 32 == 0
+        assert K.last_conv_path() == ("winograd43r" if split else "winograd43")
         yd = K.conv2d_nhwc(xd, wd, b.to(dev), winograd=False, **kw)
+        if split:                                    # ... and the unsplit form (a whole ragged tile column) still agrees
+            yu = K.conv2d_nhwc(xd, wd, b.to(dev), winograd="f43", routing=K.default_routing().replace(ragged=False), **kw)
+            assert K.last_conv_path() == "winograd43"
+            assert float((yu - yd).abs().max()) <= 2e-5 * float(ref.abs().max())
+            assert torch.equal(yu[:, :, :W - 1], yw[:, :, :W - 1]), "the full tile columns must not depend on how the last column is computed"
     else:
         ld, coff = strided
         bufw = torch.full((N, H, W, ld), 7.0, device=dev)

@@ -174,7 +174,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.glass_abi_version() == 1
+    assert L.glass_abi_version() == 2
     assert isinstance(L.glass_last_error(), bytes)
 
 
