@@ -27,6 +27,8 @@
 // glass_maxpool2d_nhwc up to fp32 summation order (tests/test_gpu_f_ops.py).
 #include "common.h"
 #include <cstdint>
+#include <type_traits>
+#include <utility>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -40,7 +42,7 @@ constexpr int RS = 3 * RPX;                      // floats per ring row (1560: e
 constexpr int SCOLS = XCOLS + 1;                 // pooling tile columns (0 = left halo)
 constexpr int LDS_RING = RING * RS;              // floats
 constexpr int LDS_S = SCOLS * 64;
-constexpr int LDS_HP = 2 * 4 * 64;          // halo partial sums, double-buffered by row parity
+constexpr int LDS_HP = 2 * 8 * 64;               // halo partial sums [wavefront][kg][channel], double-buffered by row parity
 constexpr int STEM_LDS_BYTES = (LDS_RING + LDS_S + LDS_HP) * 4;
 constexpr int LPT = (RPX + 255) / 256;           // float4 loads per thread and input row (3)
 
@@ -54,11 +56,18 @@ struct BStemParams {
 
 __device__ __forceinline__ int ring_slot(int iy) { return (iy + 16 * RING) % RING; }      // iy >= -5
 
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
 __global__ __launch_bounds__(256, 1) void backbone_stem_fused_kernel(BStemParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ring = smem;                            // [RING][RS]
   float* S = smem + LDS_RING;                    // [SCOLS][64]
-  float* hpart_all = S + LDS_S;                  // [2][4][64]
+  float* hpart_all = S + LDS_S;                  // [2][4][2][64]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,14 +131,16 @@ __global__ __launch_bounds__(256, 1) void backbone_stem_fused_kernel(BStemParams
   const int a_off1 = a_off0 + 6 * 32;
   const bool mb_ok0 = cx0 + 32 * (2 * wv) < p.Wo, mb_ok1 = cx0 + 32 * (2 * wv + 1) < p.Wo;       // wavefront-uniform
 
-  f32x16 prev[2][2], mx[2][2];                   // [M-block][N-block]: the last odd row / the running 3-row maximum
-  float hprev = -INFINITY, hmax = -INFINITY;     // the same for the halo column (threads 0 .. 63: channel = tid)
+  // [M-block][N-block]: after an odd row 2 py - 1 it holds that row (the "row above" of pooled row py); the even row 2 py is
+  // folded INTO it (max), and the odd row 2 py + 1 closes the pooled row: max(prev, row) goes out, the row itself stays
+  f32x16 prev[2][2];
+  float hprev = -INFINITY;                       // the same for the halo column (threads 0 .. 63: channel = tid)
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { prev[mb][nb][e] = -INFINITY; mx[mb][nb][e] = -INFINITY; }
+      for (int e = 0; e < 16; ++e) prev[mb][nb][e] = -INFINITY;
 
   for (int oy = oy_first; oy <= oy_last; ++oy) {
     // (1) next row's two new input rows: global -> registers (consumed at (4))
@@ -137,24 +148,31 @@ __global__ __launch_bounds__(256, 1) void backbone_stem_fused_kernel(BStemParams
     const bool more = oy < oy_last;
     if (more) { fetch_row(2 * oy + 4, nv0); fetch_row(2 * oy + 5, nv1); }
 
-    // (2) left halo column cx0 - 1 on the vector ALU: channel = lane (64 channels = 64 lanes), filter rows split by wavefront.
+    // (2) left halo column cx0 - 1 on the vector ALU, from the B fragments this lane already holds (no weight loads): lane
+    // (kg, col) owns W[32 nb + col][ky][12 kg + s], i.e. half of the 24-float filter row of two channels; filter rows are split
+    // over the wavefronts (2, 2, 2, 1), the 4 x 2 partial sums per channel are added in a fixed order at (5).
     // (double-buffered by row parity: wavefront 0 reads row oy's parts at (5) while the others may already write row oy + 1's)
-    float* hpart = hpart_all + (oy & 1) * 256;
+    float* hpart = hpart_all + (oy & 1) * 512;
     if (has_halo) {
-      const int ky0 = 2 * wv, ky1 = min(2 * wv + 2, 7);
-      float acc = 0.f;
-      for (int ky = ky0; ky < ky1; ++ky) {
-        const float* r = ring + ring_slot(2 * oy - 3 + ky) * RS;            // halo column: floats 0 .. 20 of the row
-        const float4* wg = reinterpret_cast<const float4*>(p.w) + ((long)lane * 7 + ky) * 7;
+      float h0 = 0.f, h1 = 0.f;
+      auto halo_ky = [&](auto ky_) {
+        constexpr int ky = decltype(ky_)::value;
+        const float* r = ring + ring_slot(2 * oy - 3 + ky) * RS + 12 * kg;      // halo column: floats 0 .. 23 of the row
+        const float4 i0 = *reinterpret_cast<const float4*>(r), i1 = *reinterpret_cast<const float4*>(r + 4),
+                     i2 = *reinterpret_cast<const float4*>(r + 8);
+        const float in[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-          const float4 wv4 = wg[kx];
-          acc = __builtin_fmaf(r[3 * kx], wv4.x, acc);
-          acc = __builtin_fmaf(r[3 * kx + 1], wv4.y, acc);
-          acc = __builtin_fmaf(r[3 * kx + 2], wv4.z, acc);
+        for (int s = 0; s < 12; ++s) {
+          h0 = __builtin_fmaf(in[s], wr[ky][s][0], h0);
+          h1 = __builtin_fmaf(in[s], wr[ky][s][1], h1);
         }
-      }
-      hpart[wv * 64 + lane] = acc;
+      };
+      if (wv == 0) { halo_ky(std::integral_constant<int, 0>{}); halo_ky(std::integral_constant<int, 1>{}); }
+      else if (wv == 1) { halo_ky(std::integral_constant<int, 2>{}); halo_ky(std::integral_constant<int, 3>{}); }
+      else if (wv == 2) { halo_ky(std::integral_constant<int, 4>{}); halo_ky(std::integral_constant<int, 5>{}); }
+      else halo_ky(std::integral_constant<int, 6>{});
+      hpart[(wv * 2 + kg) * 64 + col] = h0;                 // [wavefront][kg][channel]
+      hpart[(wv * 2 + kg) * 64 + 32 + col] = h1;
     }
 
     // (3) the row's convolution: 2 M-blocks x 2 N-blocks x 84 k-steps
@@ -166,67 +184,84 @@ __global__ __launch_bounds__(256, 1) void backbone_stem_fused_kernel(BStemParams
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mb][nb][e] = 0.f;
     if (mb_ok0) {
+      // 21 groups of 4 k-steps (filter row ky = g / 3, floats 4 (g % 3) .. + 3 of the lane's 12): the NEXT group's A fragments
+      // (two ds_read2_b64: this lane's 4 floats for each M-block) are requested before this group's 16 MFMAs
+      // (an M-block past the image's right edge reads zero-filled ring pixels: finite values nobody stores)
+      auto a_ptr = [&](int g) { return ring + ring_slot(2 * oy - 3 + g / 3) * RS + 4 * (g % 3); };
+      float4 c0 = *reinterpret_cast<const float4*>(a_ptr(0) + a_off0), c1 = *reinterpret_cast<const float4*>(a_ptr(0) + a_off1);
+      static_for<0, 21>([&](auto g_) {
+        constexpr int g = decltype(g_)::value;
+        constexpr int ky = g / 3, s0 = 4 * (g % 3);
+        float4 n0 = c0, n1 = c1;
+        if constexpr (g + 1 < 21) {
+          n0 = *reinterpret_cast<const float4*>(a_ptr(g + 1) + a_off0);
+          n1 = *reinterpret_cast<const float4*>(a_ptr(g + 1) + a_off1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float a0[4] = {c0.x, c0.y, c0.z, c0.w}, a1[4] = {c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-      for (int ky = 0; ky < 7; ++ky) {
-        const float* r = ring + ring_slot(2 * oy - 3 + ky) * RS;
+        for (int h = 0; h < 4; ++h) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[h], wr[ky][s0 + h][0], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[h], wr[ky][s0 + h][1], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[h], wr[ky][s0 + h][0], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[h], wr[ky][s0 + h][1], acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = n0; c1 = n1;
+      });
+    }
+
+    // (3b) fold the row into the 3-row maxima.  Even row 2 py: prev = max(row 2 py - 1, this).  Odd row 2 py + 1: closes pooled
+    // row py - max(prev, this) goes to the pooling tile - and stays as the "row above" of pooled row py + 1.  The band's first
+    // row 2 py0 - 1 (odd) only seeds `prev`.
+    const bool odd = oy & 1;
+    const bool emit = odd && oy > 2 * py0 - 1;
+    if (!odd) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          // (an M-block past the image's right edge reads zero-filled ring pixels: finite values nobody stores)
-          const f32x2 a0 = *reinterpret_cast<const f32x2*>(r + a_off0 + 2 * j);
-          const f32x2 a1 = *reinterpret_cast<const f32x2*>(r + a_off1 + 2 * j);
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int s = 2 * j + h;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[h], wr[ky][s][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[h], wr[ky][s][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[h], wr[ky][s][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[h], wr[ky][s][1], acc[1][1], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) prev[mb][nb][e] = fmaxf(prev[mb][nb][e], acc[mb][nb][e]);
+    } else {
+      if (emit) {
+        // y-pooled row -> S[1 + column][channel]; D layout: channel = 32 nb + col, column = 32 (2 wv + mb) + (e&3) + 8 (e>>2) + 4 kg
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          if (mb == 0 ? mb_ok0 : mb_ok1) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int c_ = 32 * (2 * wv + mb) + (e & 3) + 8 * (e >> 2) + 4 * kg;
+                S[(1 + c_) * 64 + 32 * nb + col] = fmaxf(prev[mb][nb][e], acc[mb][nb][e]);
+              }
           }
         }
       }
-    }
-
-    // (3b) fold the row into the 3-row maxima.  Even row 2 py: max(previous odd row, this); odd row 2 py + 1: closes pooled
-    // row py and is kept as the "row above" of pooled row py + 1.  The band's first row 2 py0 - 1 (odd) only seeds `prev`.
-    const bool odd = oy & 1;
-    const bool emit = odd && oy > 2 * py0 - 1;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[mb][nb][e];
-          if (!odd) mx[mb][nb][e] = fmaxf(prev[mb][nb][e], v);
-          else { mx[mb][nb][e] = fmaxf(mx[mb][nb][e], v); prev[mb][nb][e] = v; }
-        }
-    if (emit) {
-      // y-pooled row -> S[1 + column][channel]; D layout: channel = 32 nb + col, column = 32 (2 wv + mb) + (e&3) + 8 (e>>2) + 4 kg
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        if (mb == 0 ? mb_ok0 : mb_ok1) {
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int c_ = 32 * (2 * wv + mb) + (e & 3) + 8 * (e >> 2) + 4 * kg;
-              S[(1 + c_) * 64 + 32 * nb + col] = mx[mb][nb][e];
-            }
-        }
-      }
+        for (int nb = 0; nb < 2; ++nb) prev[mb][nb] = acc[mb][nb];
     }
 
     // (4) the prefetched input rows -> ring (slots of rows 2 oy - 6, 2 oy - 5: not read by anybody in this row)
     if (more) { stash_row(2 * oy + 4, nv0); stash_row(2 * oy + 5, nv1); }
     __syncthreads();                                                   // ring, hpart and S (rows that emit) are complete
 
-    // (5) halo column: reduce the four filter-row parts (fixed order), fold like the main rows, publish as S column 0
+    // (5) halo column: add the 4 x 2 partial sums (fixed order), fold like the main rows, publish as S column 0
     if (tid < 64) {
       float h = -INFINITY;
-      if (has_halo) h = ((hpart[tid] + hpart[64 + tid]) + hpart[128 + tid]) + hpart[192 + tid];
-      if (!odd) hmax = fmaxf(hprev, h);
-      else { hmax = fmaxf(hmax, h); hprev = h; }
-      if (emit) S[tid] = hmax;
+      if (has_halo) {
+        h = hpart[tid];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) h += hpart[q * 64 + tid];
+      }
+      if (!odd) hprev = fmaxf(hprev, h);
+      else {
+        if (emit) S[tid] = fmaxf(hprev, h);
+        hprev = h;
+      }
     }
     if (emit) {
       __syncthreads();

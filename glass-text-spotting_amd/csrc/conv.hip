@@ -610,6 +610,9 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   // grid covers the 256 CUs at least ~2x
   const long tiles128 = (long)cdiv(p.M, 128) * cdiv(d->Cout, 128);
   if (p.M <= 2048 && tiles128 < 640 && d->Cout >= 256) return launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);   // 64 x 64: few-row GEMMs (box head fc on 800 rows)
+  // the last-column strip of a 16 x 33 map (M = 4096 rows, K = 1536, Cout = 256; ops/native.py _last_column_strip): 64 x 128
+  // tiles would be 128 workgroups = half the chip at 48 k-tiles each
+  if (p.M <= 8192 && tiles128 < 128 && d->Cout >= 256) return launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);
   if (p.M <= 64 || tiles128 < 640) return launch_conv_impl<1, 4, 2, 1, 1, 4, 32>(p, s);   // 64 x 128
   return launch_conv_impl<2, 2, 2, 2, 1, 3, 32>(p, s);                      // 128 x 128, 3 blocks/CU
   // (measured on MI355X: BK=64 with 2 blocks/CU and a 2-stage LDS pipeline are both within 2% of this)
