@@ -35,9 +35,6 @@ struct ConvParams {
   unsigned x_bytes, w_bytes;      // buffer sizes for the bounds-checked load paths (0: tensors too large)
   unsigned y_bytes, r_bytes;      // output / residual spans of the vector epilogue (it is enabled only if they fit 31 bits)
   unsigned magic_cin, magic_kw;   // floor(2^32 / Cin), floor(2^32 / KW) for the per-thread tap decode (MODE 2)
-  int ldw;                        // floats between two output channels' filters (= Ktot; the FULL K of a split-K launch)
-  int ksplit;                     // > 1: split-K GEMM (glass_linear_splitk): blockIdx.y = k-slice, see split_* below
-  long split_k, split_y;          // k-slice s reads x + s * split_k / w + s * split_k and writes y + s * split_y
   int half_mode;                  // 1: fp16 operands on v_mfma_f32_32x32x16_f16 (glass_conv2d_nhwc_f16)
   int xh, yh, rh;                 // half_mode only (glass_conv2d_nhwc_h16): x / y / residual are fp16 tensors in HBM
 };
@@ -61,13 +58,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK, int MODE, bool HALF>
-__global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams pin) {
-  ConvParams p = pin;
-  if (pin.ksplit > 1) {           // split-K (linear layers): this workgroup's k-slice; partial sums go to slice s of the workspace
-    p.x += (long)blockIdx.y * pin.split_k;
-    p.w += (long)blockIdx.y * pin.split_k;
-    p.y += (long)blockIdx.y * pin.split_y;
-  }
+__global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   constexpr bool FAST = MODE == 1, BUF = MODE != 0;
   constexpr int LDS_LD = HALF ? BK + 8 : BK + 4;      // elements (halfs / floats) per staged row incl. the conflict pad
   constexpr int KCH = BK / 4;            // 16-byte chunks per staged row
@@ -127,7 +118,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams pin) {
   for (int i = 0; i < B_LOADS; ++i) {
     const int co = n0 + r0 + RPP * i;
     b_ok[i] = co < p.Cout;
-    b_off[i] = (long)(b_ok[i] ? co : 0) * p.ldw + cc * 4;
+    b_off[i] = (long)(b_ok[i] ? co : 0) * p.Ktot + cc * 4;
   }
 
   float4 areg[A_LOADS], breg[B_LOADS];
@@ -500,13 +491,12 @@ static int launch_conv_cfg(ConvParams& p, hipStream_t stream) {
     return GLASS_EINVAL;
   }
   p.nk = cdiv(p.Ktot, BK);
-  const dim3 grid((unsigned)nblk, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
   if (p.x_bytes != 0 && p.Cin % BK == 0)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 1, HALF>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 1, HALF>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   else if (p.x_bytes != 0)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 2, HALF>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 2, HALF>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   else if constexpr (!HALF)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 0, false>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 0, false>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
   else {
     glass_set_error("glass_conv2d_nhwc_f16: tensors of 2 GiB and more are not supported in the fp16 mode");
     return GLASS_EINVAL;
@@ -577,7 +567,6 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   GLASS_CHECK_ARG(M < 0x7fffffffL, "glass_conv2d_nhwc: too many output pixels");
   p.M = (int)M;
   p.Ktot = d->KH * d->KW * d->Cin;
-  p.ldw = p.Ktot; p.ksplit = 1; p.split_k = 0; p.split_y = 0;
   {
     // the buffer-load paths need 31-bit byte offsets (MODE 1 additionally Cin % 32 == 0, checked at launch)
     // (offsets are computed as fp32 byte offsets and halved for fp16 tensors: the fp32-sized span must fit 31 bits)
@@ -627,76 +616,4 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   if (p.M <= 64 || tiles128 < 640) return launch_conv_impl<1, 4, 2, 1, 1, 4, 32>(p, s);   // 64 x 128
   return launch_conv_impl<2, 2, 2, 2, 1, 3, 32>(p, s);                      // 128 x 128, 3 blocks/CU
   // (measured on MI355X: BK=64 with 2 blocks/CU and a 2-stage LDS pipeline are both within 2% of this)
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------- split-K
-// y = act(x [M,K] @ w [Nout,K]^T + bias) for FEW rows and a LONG K (box head fc1: M = 100 RoIs x 8 images, K = 256 x 7 x 7 =
-// 12544, Nout = 2048; reference recognizers_hybrid_head.py:320-322 -> d2 FastRCNNConvFCHead): 64 x 64 tiles give 416
-// workgroups of 392 sequential k-tiles each - 1.6 per CU, nothing to hide a k-tile's load -> LDS -> barrier latency behind
-// (0.43 ms at 95 TFLOP/s).  Split into `splits` k-slices (grid.y) the same kernel runs 416 x splits workgroups; slice s writes
-// its partial sums to workspace[s][M][Nout], a second kernel adds them IN SLICE ORDER (deterministic), the bias and the ReLU.
-namespace {
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long mn4, int n4,
-                                                            const float* __restrict__ bias, int relu, float* __restrict__ y) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn4; i += (long)gridDim.x * blockDim.x) {
-    float4 a = reinterpret_cast<const float4*>(ws)[i];
-    for (int s = 1; s < splits; ++s) {
-      const float4 v = reinterpret_cast<const float4*>(ws)[(long)s * mn4 + i];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    if (bias) {
-      const float4 b = reinterpret_cast<const float4*>(bias)[i % n4];
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-    reinterpret_cast<float4*>(y)[i] = a;
-  }
-}
-}  // namespace
-
-extern "C" int64_t glass_linear_splitk_workspace_bytes(int M, int Nout, int splits) {
-  return (int64_t)splits * M * Nout * (int64_t)sizeof(float);
-}
-
-extern "C" int glass_linear_splitk_supported(int M, int K, int Nout, int splits) {
-  return M > 0 && Nout > 0 && Nout % 64 == 0 && splits >= 2 && splits <= 16 && K % (32 * splits) == 0 &&
-         (long)M * K * 4 < 0x7fffff00L && (long)Nout * K * 4 < 0x7fffff00L && (long)M * Nout * 4 < 0x7fffff00L;
-}
-
-extern "C" int glass_linear_splitk(const float* x, const float* w, const float* bias, float* y, int M, int K, int Nout, int relu,
-                                   int splits, void* workspace, int64_t workspace_bytes, glass_stream_t stream) {
-  GLASS_CHECK_ARG(x && w && y && workspace, "glass_linear_splitk: null pointer");
-  GLASS_CHECK_ARG(glass_linear_splitk_supported(M, K, Nout, splits),
-                  "glass_linear_splitk: needs Nout %% 64 == 0, K %% (32 * splits) == 0, 2 <= splits <= 16 and operands < 2 GiB "
-                  "(got M=%d K=%d Nout=%d splits=%d)", M, K, Nout, splits);
-  GLASS_CHECK_ARG(workspace_bytes >= glass_linear_splitk_workspace_bytes(M, Nout, splits), "glass_linear_splitk: workspace too small");
-  GLASS_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)workspace) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0),
-                  "glass_linear_splitk: pointers must be 16-byte aligned");
-  GLASS_CHECK_ARG(relu == 0 || relu == 1, "glass_linear_splitk: relu must be 0 or 1");
-  const int ks = K / splits;
-  ConvParams p;
-  p.half_mode = 0; p.xh = p.yh = p.rh = 0;
-  p.x = x; p.w = w; p.bias = nullptr; p.res = nullptr; p.y = static_cast<float*>(workspace);
-  p.N = M; p.H = 1; p.W = 1; p.Cin = ks; p.Cout = Nout; p.KH = 1; p.KW = 1; p.sh = p.sw = 1; p.ph = p.pw = 0; p.Ho = p.Wo = 1;
-  p.ldx = K; p.ldy = Nout; p.ycoff = 0; p.ycs = 1; p.relu = 0; p.res_mode = 0; p.ldr = 0;
-  p.M = M; p.Ktot = ks; p.ldw = K; p.ksplit = splits; p.split_k = ks; p.split_y = (long)M * Nout;
-  // buffer ranges as seen from a slice's base pointers (slice s starts s * ks floats in: the span of the LAST row still ends
-  // inside the tensor, earlier slices' declared ranges end before the tensor does)
-  p.x_bytes = (unsigned)(((long)(M - 1) * K + ks) * 4);
-  p.w_bytes = (unsigned)(((long)(Nout - 1) * K + ks) * 4);
-  p.magic_cin = (unsigned)(0x100000000ULL / (unsigned long long)ks);
-  p.magic_kw = 0xffffffffu;
-  p.vec_epi = 1;
-  p.y_bytes = (unsigned)((long)M * Nout * 4);
-  p.r_bytes = 0;
-  hipStream_t s = (hipStream_t)stream;
-  const int rc = launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);          // 64 x 64 tiles, 8 workgroups per CU
-  if (rc != GLASS_OK) return rc;
-  const long mn4 = (long)M * Nout / 4;
-  const int blocks = (int)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(workspace), splits, mn4, Nout / 4,
-                     bias, relu, y);
-  GLASS_CHECK_LAUNCH("glass_linear_splitk");
-  return GLASS_OK;
 }

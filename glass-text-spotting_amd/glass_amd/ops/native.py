@@ -100,13 +100,12 @@ class Routing:
       local_stem  the fused conv0_1 + conv0_2 + maxpool kernel of the local extractor (GLASS_LOCAL_STEM=0: three launches)
       stem        the fused 7x7 conv + ReLU + max-pool kernel of the ResNet stem (GLASS_BACKBONE_STEM=0: two launches)
       ragged      maps of width 4 k + 1 on the F(4x4) kernel: full tile columns there + the last pixel column as a strip
-                  convolution (GLASS_W43_RAGGED=0: a whole extra tile column, as in rounds 2-3)
-      splitk      few-row / long-K linear layers (box head fc1) as a 4-slice split-K GEMM (GLASS_SPLITK=0: one slice)"""
-    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "splitk")
+                  convolution (GLASS_W43_RAGGED=0: a whole extra tile column, as in rounds 2-3)"""
+    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged")
 
     def __init__(self, precision: Optional[str] = None, winograd: Optional[bool] = None, f43: Optional[bool] = None, pw=None,
                  h16: Optional[bool] = None, local_stem: Optional[bool] = None, stem: Optional[bool] = None,
-                 ragged: Optional[bool] = None, splitk: Optional[bool] = None):
+                 ragged: Optional[bool] = None):
         e = os.environ.get
         self.precision = precision or e("GLASS_CONV_PRECISION", "fp32")
         if self.precision not in _PRECISIONS:
@@ -118,7 +117,6 @@ class Routing:
         self.local_stem = (e("GLASS_LOCAL_STEM", "1") != "0") if local_stem is None else bool(local_stem)
         self.stem = (e("GLASS_BACKBONE_STEM", "1") != "0") if stem is None else bool(stem)
         self.ragged = (e("GLASS_W43_RAGGED", "1") != "0") if ragged is None else bool(ragged)
-        self.splitk = (e("GLASS_SPLITK", "1") != "0") if splitk is None else bool(splitk)
 
     def replace(self, **kw) -> "Routing":
         r = Routing.__new__(Routing)
@@ -490,17 +488,6 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
                       "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd", x, _packed(w, wt, False))
     if winograd:
         raise GlassLibraryError("winograd=True but glass_winograd_supported() rejects this layer")
-    if (KH == 1 and KW == 1 and H == 1 and W == 1 and ldx == Cin and residual is None and relu in (0, 1) and out_coff == 0 and
-            out_cstride == 1 and out.shape[3] == Cout and out.dtype == torch.float32 and _use_splitk(rt, N, Cin, Cout)):
-        # a linear layer with few rows and a long K (box head fc1): split-K GEMM, partial sums through a workspace
-        nbytes = int(lib().glass_linear_splitk_workspace_bytes(N, Cout, SPLITK))
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-        _TLS.last_path = "direct"
-        check(lib().glass_linear_splitk(c_void_p(_dev(x, "x")), c_void_p(_dev(wt, "w")),
-                                        c_void_p(_dev(bias, "bias") if bias is not None else None), c_void_p(_dev(out, "out")), N, Cin,
-                                        Cout, int(relu), SPLITK, c_void_p(_dev(ws)), ctypes.c_int64(nbytes), c_void_p(stream_handle())),
-              "glass_linear_splitk")
-        return out
     return launch("glass_conv2d_nhwc", "direct", x, wt)
 
 
@@ -521,24 +508,12 @@ def _last_column_strip(x: torch.Tensor, wcol: torch.Tensor, bias, residual, out:
                                   c_void_p(stream_handle())), "glass_conv2d_nhwc(last column)")
 
 
-SPLITK = 4        # k-slices of the split-K linear path (box head fc1: K = 12544 = 4 x 98 k-tiles)
-
-
-def _use_splitk(rt: Routing, M: int, K: int, Nout: int) -> bool:
-    """few rows, long K, fp32: the box head's fc1 (800 x 12544 -> 2048).  416 workgroups x 392 k-tiles leave every CU with one
-    or two latency-bound workgroups (0.43 ms at 95 TFLOP/s); 4 k-slices give it 1664."""
-    return (rt.precision == "fp32" and rt.splitk and 0 < M <= 2048 and K >= 4096 and Nout >= 256 and
-            bool(lib().glass_linear_splitk_supported(M, K, Nout, SPLITK)))
-
-
 def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, relu: int = 0,
-           out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, precision: Optional[str] = None,
-           routing: Optional[Routing] = None) -> torch.Tensor:
-    """x [M,K] @ w[Nout,K]^T + bias on the same MFMA kernel (H = W = KH = KW = 1); few-row / long-K fp32 layers go through
-    glass_linear_splitk (conv2d_nhwc routes them)."""
+           out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, precision: Optional[str] = None) -> torch.Tensor:
+    """x [M,K] @ w[Nout,K]^T + bias on the same MFMA kernel (H = W = KH = KW = 1)."""
     M, K = x.shape
     y = conv2d_nhwc(x.view(M, 1, 1, K), w if isinstance(w, ConvWeight) else w.view(w.shape[0], 1, 1, K), bias, relu=relu,
-                    out=None if out is None else out.view(M, 1, 1, -1), out_dtype=out_dtype, precision=precision, routing=routing)
+                    out=None if out is None else out.view(M, 1, 1, -1), out_dtype=out_dtype, precision=precision)
     return y.view(M, -1)
 
 

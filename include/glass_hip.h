@@ -169,17 +169,6 @@ int glass_local_stem_fused(const float* x, const float* w1, const float* b1, con
 int glass_local_stem_fused_h16(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
                                int R, int H, int W, glass_stream_t stream);
 
-/* Split-K linear layer for FEW rows and a LONG K - the box head's fc1 (reference
- * glass/modeling/fusion/recognizers_hybrid_head.py:320-322 -> d2 FastRCNNConvFCHead [d2-recall]: 800 x 12544 -> 2048):
- * y [M,Nout] = act(x [M,K] @ w [Nout,K]^T + bias), the K range cut into `splits` slices that run as independent workgroups of
- * the implicit-GEMM kernel (partial sums in `workspace`: glass_linear_splitk_workspace_bytes) and are added in slice order by
- * a second kernel together with the bias and the ReLU - deterministic, fp32; equals glass_conv2d_nhwc on the same operands up
- * to fp32 summation order.  glass_linear_splitk_supported: Nout % 64 == 0, K % (32 * splits) == 0, 2 <= splits <= 16.        */
-int glass_linear_splitk_supported(int M, int K, int Nout, int splits);
-int64_t glass_linear_splitk_workspace_bytes(int M, int Nout, int splits);
-int glass_linear_splitk(const float* x, const float* w, const float* bias, float* y, int M, int K, int Nout, int relu, int splits,
-                        void* workspace, int64_t workspace_bytes, glass_stream_t stream);
-
 /* Fused ResNet stem (detectron2 BasicStem, [d2-recall], as restated in oracle/glass_cpu.py resnet50_fpn):
  * conv 7x7 stride 2 pad 3 (3 -> 64, BatchNorm folded into w / bias) + ReLU + max_pool2d(3, 2, 1) in ONE kernel
  * (csrc/backbone_stem.hip) - the [N,H/2,W/2,64] map between them stays on the CU.  x [N,H,W,4] NHWC4 (4th channel ignored),

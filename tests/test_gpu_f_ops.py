@@ -161,34 +161,6 @@ def test_winograd43_ragged_width_split_vs_torch(R, H, W, Cin, Cout, relu, use_re
     assert e_body <= 2e-5 and e_last <= 2e-5
 
 
-@pytest.mark.parametrize("M,Kdim,Nout,relu", [(800, 12544, 2048, 1), (100, 12544, 2048, 1), (37, 4096, 256, 0), (2048, 8192, 320, 1)])
-def test_linear_splitk_matches_single_slice_and_torch(M, Kdim, Nout, relu):
-    """glass_linear_splitk (box head fc1, reference recognizers_hybrid_head.py:320-322: few rows, K = 256 x 7 x 7): four k-slices
-    as independent workgroups + an ordered reduction with bias / ReLU, against the single-slice kernel and torch CPU fp64; the
-    result is deterministic (two runs bit-identical)."""
-    from glass_amd.ops import native as K
-    dev = _dev()
-    x = _rand((M, Kdim), 41)
-    w = _rand((Nout, Kdim), 42, (2.0 / Kdim) ** 0.5)
-    b = _rand((Nout,), 43, 0.1)
-    ref = x.double() @ w.double().t() + b.double()
-    if relu:
-        ref = F.relu(ref)
-    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
-    assert K._use_splitk(K.default_routing(), M, Kdim, Nout)
-    y = K.linear(xd, wd, bd, relu=relu)
-    y2 = K.linear(xd, wd, bd, relu=relu)
-    u = K.linear(xd, wd, bd, relu=relu, routing=K.default_routing().replace(splitk=False))
-    torch.cuda.synchronize()
-    assert torch.equal(y, y2)
-    scale = float(ref.abs().max())
-    e, eu = float((y.cpu().double() - ref).abs().max()) / scale, float((u.cpu().double() - ref).abs().max()) / scale
-    print(f"split-K linear [{M},{Kdim}]->{Nout}: max err / range = {e:.2e} (single slice {eu:.2e})")
-    assert e <= 2e-6 and float((y - u).abs().max()) <= 2e-6 * scale
-    # a layer the split does not take: K too short
-    assert not K._use_splitk(K.default_routing(), 800, 2048, 2048)
-
-
 def test_backbone_stem_fused_matches_the_two_launches_and_torch():
     """glass_backbone_stem_fused (conv 7x7 s2 p3 + bias + ReLU + max_pool2d(3, 2, 1) in one kernel, csrc/backbone_stem.hip) against
     the two launches it replaces and, on the smaller shapes, against torch CPU fp64 - shapes that cross the kernel's seams: more
