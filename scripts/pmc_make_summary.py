@@ -26,7 +26,8 @@ KEYS = {"conv_h16_kernel": "conv_h16_kernel", "local_stem_fused_h16": "local_ste
         "maxpool_h16": "maxpool_nhwc_kernel"} if HALF else {"conv3x3_wino43_f32": "conv3x3_wino43_f32", "conv1x1_pw_f32": "conv1x1_pw_f32", "conv3x3_wino128_f32": "conv3x3_wino128_f32", "conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, 1",
         "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, 1",
         "conv_igemm_f32_128x64": "conv_igemm_f32<2, 2, 2, 1, 1, 4, 32, 1",
-        "conv_igemm_f32_64x64": "conv_igemm_f32<2, 2, 1, 1, 1, 8, 32, 1"}
+        "conv_igemm_f32_64x64": "conv_igemm_f32<2, 2, 1, 1, 1, 8, 32, 1",
+        "backbone_stem_fused_kernel": "backbone_stem_fused_kernel", "local_stem_fused_kernel": "local_stem_fused_kernel<false>"}
 
 
 def _inst_ok(kernel, sub):
