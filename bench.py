@@ -569,6 +569,11 @@ def main():
                          "executed_tflops": ent["executed_tflops"], "executed_frac": ent["executed_frac"],
                          "traffic": ent["traffic"],
                          "traffic_note": pmc_note,
+                         # the HBM side of the same kernel: PMC bytes per launch / its average launch time, against the 8 TB/s
+                         # nominal peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a streaming kernel sustains) - with `frac` this
+                         # says which roofline, if any, binds: both well below 1 = issue / latency / power-bound
+                         "hbm_tbps": (ent["traffic"] / (ent["avg_launch_ms"] * 1e-3) / 1e12) if ent["traffic"] else None,
+                         "hbm_frac_of_peak": (ent["traffic"] / (ent["avg_launch_ms"] * 1e-3) / 8e12) if ent["traffic"] else None,
                          "mfma_util_percent_pmc": ent["mfma_util_percent_pmc"],
                          "launches_per_step": ent["launches_per_step"],
                          "algorithmic_gflop_per_launch": ent["algorithmic_gflop_per_launch"],
