@@ -424,7 +424,7 @@ extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const flo
 }
 
 // Only the FULL 4-column tile columns: output columns [0, 4 * (W / 4)) of every row.  A map whose width is 4 k + 1 (the local
-// extractor's 16 x 33 maps, reference local_feature_extraction.py:124 `MaxPool2d(2, (2, 1), (0, 1))`) otherwise pays a whole
+// extractor's 16 x 33 maps, reference local_feature_extraction.py:123 `MaxPool2d(2, (2, 1), (0, 1))`) otherwise pays a whole
 // tile column - 36 multiplies per tile, exactly the direct convolution of its 16 outputs - for ONE pixel column, and its
 // tile count (36 per map instead of 32) turns 4 rounds of workgroups into 4.5; the caller computes the last column with
 // glass_conv2d_nhwc on the 2-column strip (KH = 3, KW = 1 over channels = (kw, cin); ops/native.py conv2d_nhwc).

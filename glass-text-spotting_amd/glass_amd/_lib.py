@@ -39,7 +39,7 @@ class GlassLibraryError(RuntimeError):
 # Device code is compiled WITHOUT packed-f32 (v_pk_*_f32) and fma_mix instruction selection.  On MI355X / ROCm 7.2 a VOP3P
 # instruction whose low-result selector is non-zero (`v_pk_mul_f32 ... op_sel:[0,1]`, hipcc's code for float2 / float4
 # arithmetic that crosses halves) returns a wrong low half in lanes 48..63 whenever a wavefront of ANOTHER kernel issues a
-# double-rate f16 / bf16 MFMA on the same SIMD - i.e. whenever an fp16-mode step is in flight beside this one (DESIGN.md
+# double-rate f16 / bf16 MFMA on the same SIMD - i.e. whenever an fp16-mode step is in flight beside this one (docs/DESIGN_history_r1-r3.md
 # "co-resident MFMA erratum"; scripts/micro/pk_vs_convh16.hip reproduces it without any code of this library).  No code
 # inside the victim kernel can prevent it, so the instruction class is not generated at all; tests/test_isa_guard.py
 # disassembles the built library and fails on any such instruction.  (The host pass prints "'-packed-fp32-ops' is not a

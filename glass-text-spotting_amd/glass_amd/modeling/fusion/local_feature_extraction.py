@@ -45,7 +45,7 @@ class ResNetFeatureExtractor(InferenceModule):
         w["conv0_1"] = fold_conv(sd, p + "conv0_1", p + "bn0_1", device)
         w["conv0_2"] = fold_conv(sd, p + "conv0_2", p + "bn0_2", device)
         for li, nblk in _LAYERS:
-            # layer3 / layer4 (and conv3) run behind maxpool3 = MaxPool2d(2, (2, 1), (0, 1)) (reference :124): width W/4 + 1,
+            # layer3 / layer4 (and conv3) run behind maxpool3 = MaxPool2d(2, (2, 1), (0, 1)) (reference :123): width W/4 + 1,
             # i.e. 33 for the 128-pixel crops of every config - a 4 k + 1 map: these layers carry the last-column strip weights
             rg = li >= 3
             for b in range(nblk):

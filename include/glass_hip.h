@@ -135,7 +135,7 @@ int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, float* u_pa
 int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                   const float* residual, float* y, glass_stream_t stream);
 /* the same kernel restricted to the FULL tile columns: writes output columns [0, 4 * (W / 4)) only (W >= 4).  For maps of
- * width 4 k + 1 - the local extractor's 16 x 33 maps (reference glass/modeling/fusion/local_feature_extraction.py:124,
+ * width 4 k + 1 - the local extractor's 16 x 33 maps (reference glass/modeling/fusion/local_feature_extraction.py:123,
  * MaxPool2d(2, (2, 1), (0, 1)); 17 launches per step) - the ragged tile column would cost a full column of tiles for one
  * pixel column; the caller computes that column with glass_conv2d_nhwc on the last two input columns (KH 3, KW 1 over
  * channels = (kw, cin), see glass_amd/ops/native.py).  Same descriptor (the TRUE H, W), epilogue and errors.          */

@@ -6,7 +6,7 @@ synchronous run on the driver box (tests/test_gpu_z_pipeline.py::test_conv_preci
                                                                    order; the FIRST diverging launch of a failing step is named
   --order fp16 | fp32 | mixed     which models are interleaved          --prio same   both pipeline streams in the normal class
   --h16 0                         fp16 mode without conv_h16_kernel     --depth N
-Result (profiles/r03_fp16_pipeline_rootcause.log): a packed-f32 / double-rate-MFMA hardware interaction, DESIGN.md section 4.
+Result (profiles/r03_fp16_pipeline_rootcause.log): a packed-f32 / double-rate-MFMA hardware interaction, docs/DESIGN_history_r1-r3.md section 4.
 (Round 2 also had `--fill`: 600 dummy entries in the then-global packed-weight cache, to rule eviction out; the cache is gone.)
 """
 import argparse

@@ -120,7 +120,7 @@ WINO43_CASES = [
     (3, 7, 9, 16, 128, 1, True, None),            # Cin = 16 (strip K = 3 x 32)
 ])
 def test_winograd43_ragged_width_split_vs_torch(R, H, W, Cin, Cout, relu, use_res, strided):
-    """Maps of width 4 k + 1 (reference local_feature_extraction.py:124: MaxPool2d(2, (2, 1), (0, 1)) -> 16 x 33): the F(4x4,3x3)
+    """Maps of width 4 k + 1 (reference local_feature_extraction.py:123: MaxPool2d(2, (2, 1), (0, 1)) -> 16 x 33): the F(4x4,3x3)
     kernel on the full tile columns (glass_conv3x3_winograd43_body_nhwc) + the last pixel column as glass_conv2d_nhwc over the
     last two input columns, against torch CPU fp64 - every column, the last one in particular - with the layer's weights
     prepared ONCE (the load-time 'col1' pack: no launch packs anything)."""

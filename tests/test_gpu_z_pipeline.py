@@ -81,7 +81,7 @@ def test_conv_precision_does_not_leak_between_in_flight_steps():
     ref = {p: drive(make(p)()) for p in ("fp32", "fp16")}
     assert not torch.equal(ref["fp32"], ref["fp16"])
     # 12 rounds of each schedule: with the round-2 library (packed-f32 instructions in RoIAlign / decoder / NMS, corrupted
-    # by the other step's fp16 MFMAs: DESIGN.md "co-resident MFMA erratum") a round failed with probability 0.2 (mixed) / 0.6
+    # by the other step's fp16 MFMAs: docs/DESIGN_history_r1-r3.md "co-resident MFMA erratum") a round failed with probability 0.2 (mixed) / 0.6
     # (all fp16) - one round, as this test used to run, passed on the builder's box and failed on the driver's
     for order in (["fp16", "fp32", "fp16", "fp16", "fp32", "fp32", "fp16"], ["fp16"] * 7):
         for rnd in range(12):
