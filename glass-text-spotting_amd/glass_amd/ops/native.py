@@ -467,8 +467,10 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
         # the Winograd kernel runs one 64-tile x 64-channel workgroup per CU: below ~96 workgroups (FPN p6, batch-2 res5)
         # the direct kernel's smaller tiles fill the chip better (measured 0.68-0.82x vs 1.15x at 128 workgroups)
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
+    # (a model's layer takes the split only if its load prepared the strip weights - fold_conv(..., ragged=True) - so that no
+    #  launch of the model path ever packs; raw tensors (tests, scripts) get them packed for the launch)
     ragged = (rt.ragged and KH == 3 and KW == 3 and W % 4 == 1 and W >= 5 and (2 * Cin) % 32 == 0 and out_cstride == 1 and
-              res_mode in (0, 1) and x.numel() > 0)
+              ldx == Cin and res_mode in (0, 1) and x.numel() > 0 and (not isinstance(w, ConvWeight) or "col1" in w.packs))
     f43 = winograd == "f43" or (winograd is None and rt.f43 and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin, ragged))
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
         if ragged:
@@ -496,8 +498,7 @@ def _last_column_strip(x: torch.Tensor, wcol: torch.Tensor, bias, residual, out:
     pixel of W*ld channels - input channels [(W-2)*ldx, W*ldx) = the last two columns (needs ldx == Cin: dense rows), output
     channels [(W-1)*ldy + y_coff, ...) and the residual likewise.  Same stream, after the body launch."""
     N, H, W, Cin, Cout = d.N, d.H, d.W, d.Cin, d.Cout
-    if d.ldx != Cin:
-        raise GlassLibraryError("ragged-width split needs a dense input (ldx == Cin)")
+    assert d.ldx == Cin, "the caller routes only dense inputs here"
     ds = ConvDesc(N, H, 1, 2 * Cin, Cout, 3, 1, 1, 1, 1, 0, H, 1, W * d.ldx, W * d.ldy, (W - 1) * d.ldy + out_coff, 1, d.relu,
                   d.res_mode, W * d.ldr if d.res_mode else 0)
     isz = x.element_size()
