@@ -32,7 +32,10 @@ __device__ __forceinline__ float4 ra_tap(const float* base, long off) {
   }
 }
 
-template <bool FH>
+// UP2: every level tensor is HALF resolution ([N,H/2,W/2,*]) and is read through nearest-neighbour x2 upsampling - p.H / p.W are
+// the UPSAMPLED dimensions, so the sampling grid, the clamps and the bilinear weights are those of the materialised upsampled
+// map and only the tap address changes ((y, x) -> (y >> 1, x >> 1)): glass_roi_align_rotated_up2.
+template <bool FH, bool UP2>
 __global__ __launch_bounds__(256) void roi_align_rotated_kernel(RoiParams p) {
   const long total = (long)p.R * p.PH * p.PW * p.C4;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -73,7 +76,8 @@ __global__ __launch_bounds__(256) void roi_align_rotated_kernel(RoiParams p) {
     const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(rw / (float)p.PW);
     const float count = (float)(gh * gw > 1 ? gh * gw : 1);
     const float start_h = -rh / 2.0f, start_w = -rw / 2.0f;
-    const long boff = (long)b * H * W * ld + c4 * 4;          // element offset of (image b, channel group c4) in the level
+    const int Ws = UP2 ? (W >> 1) : W;                        // stored row length
+    const long boff = (UP2 ? (long)b * (H >> 1) * Ws : (long)b * H * W) * ld + c4 * 4;   // (image b, channel group c4) in the level
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int iy = 0; iy < gh; ++iy) {
@@ -90,10 +94,11 @@ __global__ __launch_bounds__(256) void roi_align_rotated_kernel(RoiParams p) {
         if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
         const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
         const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        const float4 v1 = ra_tap<FH>(feat, boff + ((long)yl * W + xl) * ld);
-        const float4 v2 = ra_tap<FH>(feat, boff + ((long)yl * W + xh) * ld);
-        const float4 v3 = ra_tap<FH>(feat, boff + ((long)yh * W + xl) * ld);
-        const float4 v4 = ra_tap<FH>(feat, boff + ((long)yh * W + xh) * ld);
+        const int ya = UP2 ? (yl >> 1) : yl, yb = UP2 ? (yh >> 1) : yh, xa = UP2 ? (xl >> 1) : xl, xb = UP2 ? (xh >> 1) : xh;
+        const float4 v1 = ra_tap<FH>(feat, boff + ((long)ya * Ws + xa) * ld);
+        const float4 v2 = ra_tap<FH>(feat, boff + ((long)ya * Ws + xb) * ld);
+        const float4 v3 = ra_tap<FH>(feat, boff + ((long)yb * Ws + xa) * ld);
+        const float4 v4 = ra_tap<FH>(feat, boff + ((long)yb * Ws + xb) * ld);
         // same association order as the reference CPU op: w1*v1 + w2*v2 + w3*v3 + w4*v4
         acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
         acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void roi_align_rotated_kernel(RoiParams p) {
 }
 
 static int roi_align_launch(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R, float* out,
-                            glass_stream_t stream, bool feat_half) {
+                            glass_stream_t stream, bool feat_half, bool up2 = false) {
   GLASS_CHECK_ARG(d && out, "glass_roi_align_rotated: null pointer");
   GLASS_CHECK_ARG(d->num_levels >= 1 && d->num_levels <= 5, "glass_roi_align_rotated: num_levels=%d", d->num_levels);
   GLASS_CHECK_ARG(d->C > 0 && d->C % 4 == 0, "glass_roi_align_rotated: C=%d must be a multiple of 4", d->C);
@@ -132,10 +137,15 @@ static int roi_align_launch(const glass_roialign_desc* d, const float* boxes, co
   const long total = (long)R * p.PH * p.PW * p.C4;
   long g = (total + 255) / 256;
   if (g > 256L * 32) g = 256L * 32;
-  if (feat_half)
-    hipLaunchKernelGGL(roi_align_rotated_kernel<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+  if (up2) {
+    for (int i = 0; i < d->num_levels; ++i)
+      GLASS_CHECK_ARG(d->H[i] % 2 == 0 && d->W[i] % 2 == 0, "glass_roi_align_rotated_up2: level %d: upsampled H, W must be even", i);
+    GLASS_CHECK_ARG(!feat_half, "glass_roi_align_rotated_up2: fp32 levels only");
+    hipLaunchKernelGGL((roi_align_rotated_kernel<false, true>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (feat_half)
+    hipLaunchKernelGGL((roi_align_rotated_kernel<true, false>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL(roi_align_rotated_kernel<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((roi_align_rotated_kernel<false, false>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
   GLASS_CHECK_LAUNCH("glass_roi_align_rotated");
   return GLASS_OK;
 }
@@ -148,4 +158,14 @@ extern "C" int glass_roi_align_rotated(const glass_roialign_desc* d, const float
 extern "C" int glass_roi_align_rotated_h16(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R,
                                            float* out, glass_stream_t stream) {
   return roi_align_launch(d, boxes, batch_idx, R, out, stream, true);
+}
+
+// ROIAlignRotated of nearest_up2(level): d->feat[] are the HALF-resolution tensors, d->H / d->W / d->scale describe the upsampled
+// map.  RoIAlign is linear in the feature map and P2P3Fusion (reference fusion_modules.py:281-286: conv1x1(p2) +
+// up2(conv1x1(p3)), no bias, no norm) is linear too, so pool(conv1(p2) + up2(conv2(p3))) = W1 pool(p2) + W2 pool(up2(p3)): the
+// recognizer pooler can run on p2 and on up2(p3) directly and the two 1x1 convolutions shrink from the whole map to the pooled
+// bins (glass_amd/modeling/fusion/fusion_modules.py P2P3Fusion.pooled_nhwc).
+extern "C" int glass_roi_align_rotated_up2(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R,
+                                           float* out, glass_stream_t stream) {
+  return roi_align_launch(d, boxes, batch_idx, R, out, stream, false, true);
 }

@@ -168,13 +168,21 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
                                   roi_image: torch.Tensor, num_images: int, return_intermediates: bool = False):
         """boxes [R,5], roi_image int32 [R] -> pred_text_prob [R,26,97] (R > 0)."""
         R = boxes.shape[0]
-        g = self.recognizer_feature_fusion.forward_nhwc(feats[self.recognizer_in_features[0]],
-                                                        feats[self.recognizer_in_features[1]])
-        C = g.shape[-1]
+        p2, p3 = feats[self.recognizer_in_features[0]], feats[self.recognizer_in_features[1]]
+        fus = self.recognizer_feature_fusion
         # channel-interleaved cat(local, global): local -> even channels, global -> odd channels
-        xcat = torch.empty((R, self.rec_ph, self.rec_pw, self.local_ch + C), dtype=torch.float32, device=boxes.device)
-        K.roi_align_rotated([g], [self.rec_scale], boxes, roi_image, (self.rec_ph, self.rec_pw), self.rec_sampling_ratio,
+        if hasattr(fus, "can_pool") and fus.can_pool(p2, p3, R, self.rec_ph * self.rec_pw):
+            # pool first, fuse the pooled bins (P2P3Fusion.pooled_nhwc: both stages are linear)
+            C = fus.out_channels
+            xcat = torch.empty((R, self.rec_ph, self.rec_pw, self.local_ch + C), dtype=torch.float32, device=boxes.device)
+            fus.pooled_nhwc(p2, p3, self.rec_scale, boxes, roi_image, (self.rec_ph, self.rec_pw), self.rec_sampling_ratio,
                             out=xcat, out_coff=1, out_cstride=2)
+        else:
+            g = fus.forward_nhwc(p2, p3)
+            C = g.shape[-1]
+            xcat = torch.empty((R, self.rec_ph, self.rec_pw, self.local_ch + C), dtype=torch.float32, device=boxes.device)
+            K.roi_align_rotated([g], [self.rec_scale], boxes, roi_image, (self.rec_ph, self.rec_pw), self.rec_sampling_ratio,
+                                out=xcat, out_coff=1, out_cstride=2)
         crops = K.roi_align_rotated([img_nhwc4], [1.0], boxes, roi_image, self.img_pooler_size, self.img_sampling_ratio,
                                     channels=4)
         self._local_extractor_streams(crops, xcat)

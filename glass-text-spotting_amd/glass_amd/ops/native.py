@@ -100,12 +100,14 @@ class Routing:
       local_stem  the fused conv0_1 + conv0_2 + maxpool kernel of the local extractor (GLASS_LOCAL_STEM=0: three launches)
       stem        the fused 7x7 conv + ReLU + max-pool kernel of the ResNet stem (GLASS_BACKBONE_STEM=0: two launches)
       ragged      maps of width 4 k + 1 on the F(4x4) kernel: full tile columns there + the last pixel column as a strip
-                  convolution (GLASS_W43_RAGGED=0: a whole extra tile column, as in rounds 2-3)"""
-    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged")
+                  convolution (GLASS_W43_RAGGED=0: a whole extra tile column, as in rounds 2-3)
+      pooled_fusion  P2P3Fusion's two 1x1 convolutions AFTER the recognizer pooler (on the pooled bins) instead of on the whole
+                  p2 / p3 maps - RoIAlign and the fusion are both linear (GLASS_POOLED_FUSION=0: whole-map fusion, then pool)"""
+    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion")
 
     def __init__(self, precision: Optional[str] = None, winograd: Optional[bool] = None, f43: Optional[bool] = None, pw=None,
                  h16: Optional[bool] = None, local_stem: Optional[bool] = None, stem: Optional[bool] = None,
-                 ragged: Optional[bool] = None):
+                 ragged: Optional[bool] = None, pooled_fusion: Optional[bool] = None):
         e = os.environ.get
         self.precision = precision or e("GLASS_CONV_PRECISION", "fp32")
         if self.precision not in _PRECISIONS:
@@ -117,6 +119,7 @@ class Routing:
         self.local_stem = (e("GLASS_LOCAL_STEM", "1") != "0") if local_stem is None else bool(local_stem)
         self.stem = (e("GLASS_BACKBONE_STEM", "1") != "0") if stem is None else bool(stem)
         self.ragged = (e("GLASS_W43_RAGGED", "1") != "0") if ragged is None else bool(ragged)
+        self.pooled_fusion = (e("GLASS_POOLED_FUSION", "1") != "0") if pooled_fusion is None else bool(pooled_fusion)
 
     def replace(self, **kw) -> "Routing":
         r = Routing.__new__(Routing)
@@ -650,8 +653,9 @@ def image_u8hwc_to_chw(img: torch.Tensor, out_hw: Tuple[int, int], flip_channels
 
 def roi_align_rotated(feats: List[torch.Tensor], scales: Sequence[float], boxes: torch.Tensor, batch_idx: torch.Tensor,
                       out_size: Tuple[int, int], sampling_ratio: int, channels: Optional[int] = None,
-                      out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cstride: int = 1) -> torch.Tensor:
-    """feats: NHWC level tensors; boxes [R,5] float32; batch_idx [R] int32. Returns [R,PH,PW,C]."""
+                      out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cstride: int = 1, up2: bool = False) -> torch.Tensor:
+    """feats: NHWC level tensors; boxes [R,5] float32; batch_idx [R] int32. Returns [R,PH,PW,C].  up2: the level tensors are
+    HALF resolution and are pooled through nearest x2 upsampling (`scales` describe the upsampled map)."""
     R = boxes.shape[0]
     C = channels if channels is not None else feats[0].shape[-1]
     PH, PW = out_size
@@ -665,7 +669,7 @@ def roi_align_rotated(feats: List[torch.Tensor], scales: Sequence[float], boxes:
         if f.dtype != feats[0].dtype:
             raise GlassLibraryError("all pyramid levels of one RoIAlign call must share a dtype")
         d.feat[i] = _dev(f)
-        d.H[i], d.W[i], d.ld[i] = f.shape[1], f.shape[2], f.shape[3]
+        d.H[i], d.W[i], d.ld[i] = f.shape[1] * (2 if up2 else 1), f.shape[2] * (2 if up2 else 1), f.shape[3]
         d.scale[i] = float(s)
     d.min_level = int(round(-math.log2(scales[0])))
     d.C, d.PH, d.PW, d.sampling_ratio = C, PH, PW, int(sampling_ratio)
@@ -674,7 +678,9 @@ def roi_align_rotated(feats: List[torch.Tensor], scales: Sequence[float], boxes:
         _f32c(boxes, "boxes")
         if batch_idx.dtype != torch.int32:
             raise GlassLibraryError("batch_idx must be int32")
-        fn = lib().glass_roi_align_rotated_h16 if half else lib().glass_roi_align_rotated
+        if up2 and half:
+            raise GlassLibraryError("roi_align_rotated(up2=True) takes fp32 levels")
+        fn = lib().glass_roi_align_rotated_up2 if up2 else (lib().glass_roi_align_rotated_h16 if half else lib().glass_roi_align_rotated)
         check(fn(ctypes.byref(d), c_void_p(_dev(boxes)), c_void_p(_dev(batch_idx)), R, c_void_p(_dev(_f32c(out, "out"))),
                  c_void_p(stream_handle())), "glass_roi_align_rotated")
     return out

@@ -221,6 +221,13 @@ int glass_roi_align_rotated(const glass_roialign_desc* d, const float* boxes, co
 int glass_roi_align_rotated_h16(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R,
                                 float* out, glass_stream_t stream);
 
+/* the same on nearest_up2(level): d->feat[] are HALF-resolution fp32 tensors [N,H/2,W/2,*], d->H / d->W / d->scale describe the
+ * x2-upsampled map (even H, W): sampling grid, clamps and bilinear weights are those of the materialised upsampled map, tap
+ * (y, x) reads (y >> 1, x >> 1).  Lets the recognizer pooler (glass/modeling/fusion/recognizers_hybrid_head.py:550) read
+ * P2P3Fusion's second operand without the upsampled map existing (glass/modeling/fusion/fusion_modules.py:281-286).        */
+int glass_roi_align_rotated_up2(const glass_roialign_desc* d, const float* boxes, const int* batch_idx, int R, float* out,
+                                glass_stream_t stream);
+
 /* ------------------------------------------------------------------ rotated-box proposals
  * RRPN proposal selection for a whole batch and all pyramid levels (d2 RRPN.predict_proposals +
  * find_top_rrpn_proposals, reached from glass/modeling/meta_arch/glass_rcnn.py:87): per image and

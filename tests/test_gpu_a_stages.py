@@ -79,6 +79,39 @@ def test_p2p3_golden(model, golden_dir):
     assert _maxdiff(y.cpu().numpy(), g["y"]) < TOL
 
 
+def test_pooled_p2p3_fusion_matches_pool_of_the_reference_fused_map(model, golden_dir):
+    """Round 4: the recognizer pooler runs BEFORE P2P3Fusion's 1x1 convolutions (pool(W1 p2 + up2(W2 p3)) = W1 pool(p2) +
+    W2 pool(up2(p3)), both stages linear).  Pinned on the REFERENCE module's fused map (tests/golden/p2p3_fusion.npz, produced by
+    glass/modeling/fusion/fusion_modules.py:281-286) pooled by the oracle's ROIAlignRotated (oracle/d2ops.py, 8 x 32 bins, adaptive
+    sampling, scale 1/4 - reference recognizers_hybrid_head.py:453-469, :550): rotated, tiny, oversize and partly-outside boxes."""
+    from glass_amd.ops import native as K
+    from oracle import d2ops as D
+    g = _g(golden_dir, "p2p3_fusion.npz")
+    p2, p3, y = torch.from_numpy(g["p2"]), torch.from_numpy(g["p3"]), torch.from_numpy(g["y"])
+    N, C, H, W = p2.shape
+    side = 4.0 * H
+    boxes = torch.tensor([[0.5 * side, 0.5 * side, 0.6 * side, 0.2 * side, 0.0], [0.3 * side, 0.6 * side, 0.5 * side, 0.15 * side, 30.0],
+                          [0.7 * side, 0.4 * side, 0.3 * side, 0.5 * side, -75.0], [0.05 * side, 0.05 * side, 0.4 * side, 0.2 * side, 10.0],
+                          [0.5 * side, 0.5 * side, 1.5 * side, 1.2 * side, 45.0], [0.6 * side, 0.6 * side, 3.0, 2.0, 0.0],
+                          [0.95 * side, 0.9 * side, 0.5 * side, 0.3 * side, 170.0]], dtype=torch.float32)
+    bidx = torch.zeros((len(boxes),), dtype=torch.int32)
+    rois = torch.cat([bidx.float()[:, None], boxes], 1)
+    ref = D.roi_align_rotated(y[:1].contiguous(), rois, (8, 32), 0.25, 0)                 # [R,C,8,32]
+    fus = model.roi_heads.recognizer_feature_fusion
+    p2d, p3d = _nhwc(g["p2"][:1]), _nhwc(g["p3"][:1])
+    assert fus.can_pool(p2d.expand(64, -1, -1, -1), p3d.expand(64, -1, -1, -1), len(boxes), 256)    # (a batch large enough for the rule)
+    out = torch.zeros((len(boxes), 8, 32, 2 * C), device=_dev())
+    fus.pooled_nhwc(p2d, p3d, 0.25, boxes.to(_dev()), bidx.to(_dev()), (8, 32), 0, out=out, out_coff=1, out_cstride=2)
+    got = out[..., 1::2].permute(0, 3, 1, 2).cpu()
+    whole = torch.zeros_like(out)
+    K.roi_align_rotated([fus.forward_nhwc(p2d, p3d)], [0.25], boxes.to(_dev()), bidx.to(_dev()), (8, 32), 0, out=whole, out_coff=1, out_cstride=2)
+    scale = float(ref.abs().max())
+    e_ref = float((got - ref).abs().max()) / scale
+    e_whole = float((out - whole).abs().max()) / scale
+    print(f"[parity] pooled P2P3 fusion vs oracle pool of the reference's fused map: max err / range {e_ref:.2e}; vs pool of our fused map {e_whole:.2e}")
+    assert e_ref < 2e-5 and e_whole < 2e-5 and float(out[..., 0::2].abs().max()) == 0.0
+
+
 def test_bilstm_golden(model, golden_dir):
     g = _g(golden_dir, "bilstm_encoder.npz")
     y = model.roi_heads.recognizer_head.encoder(torch.from_numpy(g["x"]).to(_dev()))

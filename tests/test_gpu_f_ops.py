@@ -161,6 +161,28 @@ def test_winograd43_ragged_width_split_vs_torch(R, H, W, Cin, Cout, relu, use_re
     assert e_body <= 2e-5 and e_last <= 2e-5
 
 
+def test_roi_align_up2_equals_pooling_the_materialised_upsampled_map():
+    """glass_roi_align_rotated_up2: pooling a half-resolution level THROUGH nearest x2 upsampling is bit-identical to pooling the
+    materialised upsampled map (same sampling grid, clamps, weights; only the tap address differs)."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    x = _rand((3, 24, 40, 64), 51).to(dev)
+    up = x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+    g = torch.Generator().manual_seed(52)
+    R = 40
+    u = torch.rand((R, 5), generator=g)
+    boxes = torch.stack([u[:, 0] * 320, u[:, 1] * 192, 8 + u[:, 2] * 200, 4 + u[:, 3] * 90, u[:, 4] * 360 - 180], 1).float().to(dev)
+    boxes[0] = torch.tensor([-20.0, -10.0, 100.0, 60.0, 15.0])         # mostly outside
+    boxes[1] = torch.tensor([318.0, 190.0, 40.0, 30.0, -30.0])          # across the bottom-right corner (clamps at H-1 / W-1)
+    bidx = (torch.arange(R) % 3).to(torch.int32).to(dev)
+    for size, sr in (((8, 32), 0), ((7, 7), 2)):
+        a = K.roi_align_rotated([x], [0.25], boxes, bidx, size, sr, up2=True)
+        b = K.roi_align_rotated([up], [0.25], boxes, bidx, size, sr)
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        K.roi_align_rotated([x.half()], [0.25], boxes, bidx, (8, 32), 0, up2=True)
+
+
 def test_backbone_stem_fused_matches_the_two_launches_and_torch():
     """glass_backbone_stem_fused (conv 7x7 s2 p3 + bias + ReLU + max_pool2d(3, 2, 1) in one kernel, csrc/backbone_stem.hip) against
     the two launches it replaces and, on the smaller shapes, against torch CPU fp64 - shapes that cross the kernel's seams: more
