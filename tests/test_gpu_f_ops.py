@@ -196,7 +196,7 @@ def test_backbone_stem_fused_matches_the_two_launches_and_torch():
     w4[..., :3] = w.permute(0, 2, 3, 1)
     wd, bd = w4.contiguous().to(dev), b.to(dev)
     off = K.default_routing().replace(stem=False)
-    for (N, H, W) in ((2, 64, 96), (1, 36, 40), (3, 72, 1040), (1, 264, 1100), (8, 128, 544), (200, 36, 32)):   # last: 8-row bands, ragged last band (Hp = 9)
+    for (N, H, W) in ((2, 64, 96), (1, 36, 40), (3, 72, 1040), (1, 264, 1100), (8, 128, 544), (200, 36, 32), (1, 4, 4), (2, 8, 12)):   # (200, 36, 32): 8-row bands, ragged last band (Hp = 9); last two: smaller than one M-block
         x = _rand((N, 3, H, W), 33 + H, 60.0)
         x4 = torch.zeros((N, H, W, 4))
         x4[..., :3] = x.permute(0, 2, 3, 1)
