@@ -260,11 +260,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
 
   // ---- prologue: patch 0 -> V[0], weight fragments of the first three groups, patch 1 in flight ----
   static_for<36>([&](auto i_) { load_patch1(0, i_); });
+  if constexpr (!PERSIST) {
 #pragma unroll
-  for (int u = 0; u < RING - 1; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
+    for (int u = 0; u < RING - 1; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
+  }
   static_for<6>([&](auto c_) { static_for<6>([&](auto s_) { row_step(c_, s_); }); });
   static_for<6>([&](auto i_) { static_for<6>([&](auto s_) { col_step(0, i_, s_); }); });
-  {
+  if constexpr (!PERSIST) {
     const int k1 = p.nk > 1 ? 1 : 0;
     static_for<36>([&](auto i_) { load_patch1(k1, i_); });
   }
@@ -273,6 +275,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
 
   int par = 0;                                   // PERSIST: V stage that holds k-tile 0 of the current block
   for (;;) {                                     // blocks (one iteration unless PERSIST)
+  if constexpr (PERSIST) {
+    // head of every block, the first one included, so that hardly anything is live across the loop's back edge (loop-carried
+    // patch / weight registers made the register allocator permute and spill): the block's second patch and its first weight
+    // fragments - what the tail of the one-shot prologue requests
+    {
+      // nothing but scalars crosses the loop's back edge: the per-thread constants and this block's patch offsets are
+      // recomputed here from an opaque copy of the thread id
+      int tid_o = threadIdx.x;
+      asm volatile("" : "+v"(tid_o));
+      setup_thread(tid_o);
+      set_in_offsets(t0);
+    }
+    __builtin_amdgcn_sched_barrier(0);           // (the scheduler must not lift these 42 loads into the epilogue above: 96 more
+    static_for<36>([&](auto i_) { load_patch1(1, i_); });         //  live registers there spill the residual rows; nk >= 2 here)
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int i = 0; i < 36; ++i)
 #pragma unroll
@@ -365,7 +385,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   }
   // ReLU before (2) / after (1) the residual add as an unconditional max: max(x, qNaN) = x keeps "no ReLU" exact
   const float lo2 = p.relu == 2 ? 0.f : __builtin_nanf(""), lo1 = p.relu == 1 ? 0.f : __builtin_nanf("");
-  f32x4 rres[2][16];
+  // (persistent form: ONE set of residual rows, loaded per channel block right after the other block's stores - two sets did
+  //  not fit beside what lives across the block loop and were spilled to scratch, reloaded one store at a time)
+  f32x4 rres[PERSIST ? 1 : 2][16];
   auto load_res = [&](auto cb_) {
     constexpr int cb = decltype(cb_)::value;
     if (p.res_mode == 1) {
@@ -373,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          rres[cb][a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 64, 0));
+          rres[PERSIST ? 0 : cb][a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 64, 0));
     }
   };
   load_res(ic<0>{});
@@ -398,17 +420,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     }
     // the other channel block's residual rows are requested as soon as this block's accumulators are dead, a whole
     // output transform ahead of their use
-    if constexpr (cb == 0) { __builtin_amdgcn_sched_barrier(0); load_res(ic<1>{}); __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (cb == 0 && !PERSIST) { __builtin_amdgcn_sched_barrier(0); load_res(ic<1>{}); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         f32x4 v = out[a * 4 + b] + bv;
         v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
-        if (p.res_mode == 1) v = v + rres[cb][a * 4 + b];
+        if (p.res_mode == 1) v = v + rres[PERSIST ? 0 : cb][a * 4 + b];
         v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yrow[a] + ycol[b], cb * 64, 0);
       }
+    if constexpr (cb == 0 && PERSIST) { __builtin_amdgcn_sched_barrier(0); load_res(ic<1>{}); __builtin_amdgcn_sched_barrier(0); }
   });
   if constexpr (ABL == 4) {
     __builtin_amdgcn_s_waitcnt(0);
@@ -421,23 +444,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   if constexpr (!PERSIST) {
     break;
   } else {
+    __builtin_amdgcn_sched_barrier(0);
     if (nxt < 0) break;
     // ---- next block: its k-tile 0 already sits transformed in V[(par + nk) & 1]; request its second patch and its first weight
     // fragments (what the tail of the one-shot prologue does), no barrier needed (the epilogue does not touch LDS)
-    {
-      int tid_o = threadIdx.x;
-      asm volatile("" : "+v"(tid_o));            // opaque: the values derived from it are recomputed here, not kept live
-      setup_thread(tid_o);
-    }
     par = (par + p.nk) & 1;
     logical = nxt; nxt = p.nk >= 3 ? -1 : nn;
     tile_m = logical / p.tiles_n;
     tile_n = logical - tile_m * p.tiles_n;
     t0 = tile_m * T4; n0 = tile_n * N4;
-    set_in_offsets(t0);
-    static_for<36>([&](auto i_) { load_patch1(1, i_); });         // (nk >= 2 in this mode)
-#pragma unroll
-    for (int u = 0; u < RING - 1; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
   }
   }   // blocks
   if constexpr (PERSIST) {
