@@ -25,7 +25,6 @@ struct WinoParams {
   unsigned x_bytes, u_bytes, y_bytes, r_bytes;
   unsigned magic_tpi, magic_tw;    // floor(2^32 / d) for the two tile-index divisions (fast_div)
   unsigned long long* dbg;         // timing-instrumented builds only (GLASS_W43_ABL=4): per-workgroup cycle stamps
-  unsigned* ctr;                   // persistent F(4x4) launches: [0..7] per-XCD block counters, [8] workgroups done (all zero at launch)
 };
 
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }

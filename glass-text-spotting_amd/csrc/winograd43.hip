@@ -90,14 +90,7 @@ __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, floa
   y3 = __builtin_fmaf(-8.f, m4, __builtin_fmaf(0.125f, m3, d)) + m5;
 }
 
-// PERSIST (round-4 experiment, GLASS_W43_PERSIST=1): one workgroup per CU walks a list of blocks handed out by per-XCD atomic
-// counters (p.ctr) instead of one block per launch slot, and the input side of the k-loop's software pipeline simply RUNS ON into
-// the next block: the last two k-tiles of a block - which otherwise re-load and re-transform a clamped patch for nothing -
-// fetch and transform k-tile 0 of the NEXT block into the free V stage, so a block's prologue (first patch from HBM, its
-// transform, the barrier: 14-15 K of a block's ~224 K cycles at 8 k-tiles, of ~126 K at 4) costs nothing from the second block
-// on.  Nothing is kept in registers across the epilogue (the handover is the V stage in LDS); after the epilogue only the next
-// block's second patch and first weight fragments are requested.
-template <int ABL, int WT, int WC, int KT, bool PERSIST = false>   // ABL: timing ablations (GLASS_W43_ABL): 0 = product, 1 = weights from one hot chunk, 2 = no transform VALU, 3 = no patch loads, 4 = phase stamps
+template <int ABL, int WT, int WC, int KT>   // ABL: timing ablations (GLASS_W43_ABL): 0 = product, 1 = weights from one hot chunk, 2 = no transform VALU, 3 = no patch loads, 4 = phase stamps
 __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   static_assert(WT * WC == 4 && (KT == 32 || KT == 16) && 16 * WT * (KT / 2) == 256, "4 waves; one (tile, channel pair) per thread");
   constexpr int T4 = 16 * WT;                 // output tiles (4x4 pixels each) per block
@@ -112,43 +105,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   static_assert(NG % RING == 0, "ring slot = group % RING must be consistent across k-tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // XCD-aware tile map (see conv.hip): cout-blocks innermost so the blocks that share an input patch sit on one L2
-  const int nblk = PERSIST ? p.tiles_m * p.tiles_n : (int)gridDim.x, bid = blockIdx.x;
+  const int nblk = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nblk >> 3, r8 = nblk & 7;
-  const int tid = threadIdx.x, lane = tid & 63;
-  // PERSIST: XCD x owns the logical ids [start(x), start(x) + q8 + (x < r8)) - the same chunks as the one-shot mapping - and hands
-  // them out through p.ctr[x]; a workgroup whose own XCD has run dry takes from the others (thread 0 only)
-  int* ids = reinterpret_cast<int*>(smem + 2 * V4_FLOATS);      // [0], [1]: the first block ids; [2]: the id fetched ahead
-  auto fetch = [&]() -> int {
-    for (int i = 0; i < 8; ++i) {
-      const int x = (xcd + i) & 7;
-      const int cnt = q8 + (x < r8 ? 1 : 0);
-      if (cnt == 0) continue;
-      const int v = (int)atomicAdd(&p.ctr[x], 1u);
-      if (v < cnt) return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + v;
-    }
-    return -1;
-  };
-  int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  // PERSIST: `nxt` = the next block's id.  It is needed at k-tile nk - 2 (where the next block's first patch is requested) and is
-  // fetched as late as that allows - at k-tile nk - 3, or, with two k-tiles per block, at the last k-tile of the block before
-  // (then `nn` carries it over one block) - because a workgroup that sits on reserved blocks while others run dry is the tail
-  int nxt = -1, nn = -1;
-  if constexpr (PERSIST) {
-    if (tid == 0) { ids[0] = fetch(); ids[1] = p.nk == 2 ? fetch() : -1; }
-    __syncthreads();
-    logical = ids[0]; nxt = ids[1];
-    if (logical < 0) {                                            // nothing left for this workgroup
-      if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(&p.ctr[8], 1u) == gridDim.x - 1) { for (int i = 0; i < 9; ++i) p.ctr[i] = 0u; __threadfence(); }
-      }
-      return;
-    }
-  }
-  int tile_m = logical / p.tiles_n;
-  int tile_n = logical - tile_m * p.tiles_n;
-  int t0 = tile_m * T4, n0 = tile_n * N4;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = logical / p.tiles_n;
+  const int tile_n = logical - tile_m * p.tiles_n;
+  const int t0 = tile_m * T4, n0 = tile_n * N4;
 
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tpi = p.TH * p.TW;
   unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
@@ -158,13 +122,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
 
   // ---- input role: thread = (tile tl, channel pair c2 of the k-tile) ----
-  // per-thread constants: plain variables so that the persistent form can RECOMPUTE them from an opaque copy of the thread id
-  // after every epilogue instead of keeping ~20 registers alive across it (setup_thread below)
-  int c2 = tid % (KT / 2), tl = tid / (KT / 2);
+  const int c2 = tid % (KT / 2), tl = tid / (KT / 2);
   const int wc = WC == 4 ? wv : (wv & (WC - 1)), wt = WC == 4 ? 0 : (wv / WC);
   unsigned rowoff[6], coloff[6];
-  auto set_in_offsets = [&](int t0_) {           // split patch offsets of tile t0_ + tl (this thread's input tile of a block)
-    const int t = t0_ + tl;
+  {
+    const int t = t0 + tl;
     const bool tv = t < p.ntiles;
     const int n = fast_div(t, tpi, p.magic_tpi);
     const int rem = t - n * tpi;
@@ -181,8 +143,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
       const int wi = w0 + c;
       coloff[c] = ((unsigned)wi < (unsigned)p.W) ? (unsigned)((wi * p.ldx + 2 * c2) * 4) : INV;
     }
-  };
-  set_in_offsets(t0);
+  }
   f32x2 dd[36];                               // the channel pair of the 6x6 patch, transformed in place
   auto load_patch1 = [&](int kt, auto i_) {
     constexpr int i = decltype(i_)::value;
@@ -229,23 +190,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   // 16x16x4: A[i = lane&15][k = lane>>4] = weights (row i = 4 g' + e  <->  channel 32 wc + 16 cb + 4 g' + e),
   //          B[k = lane>>4][j = lane&15] = V (tile j);  C/D: lane holds rows 4 (lane>>4) + e, column lane&15.
   f32x4 acc[36][2];
+#pragma unroll
+  for (int i = 0; i < 36; ++i)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int vj = lane & 15, kg = lane >> 4;
-  int vt = 16 * wt + vj;                      // this lane's tile within the block
-  int vswz = (vt / RPW) % SLOTS;
+  const int vj = lane & 15, kg = lane >> 4;
+  const int vt = 16 * wt + vj;                // this lane's tile within the block
+  const int vswz = (vt / RPW) % SLOTS;
   const float* vb[2] = {smem + vt * K4 + ((0 * 4 + kg) ^ vswz) * 4, smem + vt * K4 + (((HALVES - 1) * 4 + kg) ^ vswz) * 4};
-  unsigned a_voff = (unsigned)lane * 16u;
-  auto setup_thread = [&](int tid_) {         // (persistent form, after an epilogue) the same values again
-    const int lane_ = tid_ & 63;
-    c2 = tid_ % (KT / 2); tl = tid_ / (KT / 2);
-    vdst = smem + tl * K4 + (((c2 >> 1) ^ ((tl / RPW) % SLOTS)) * 4) + (c2 & 1) * 2;
-    vj = lane_ & 15; kg = lane_ >> 4;
-    vt = 16 * wt + vj;
-    vswz = (vt / RPW) % SLOTS;
-    vb[0] = smem + vt * K4 + ((0 * 4 + kg) ^ vswz) * 4;
-    vb[1] = smem + vt * K4 + (((HALVES - 1) * 4 + kg) ^ vswz) * 4;
-    a_voff = (unsigned)lane_ * 16u;
-  };
+  const unsigned a_voff = (unsigned)lane * 16u;
   f32x4 aq[RING][2];                          // weight fragments: [ring slot = group % RING][cb]
   f32x4 vq[2];                                // V fragments: [group & 1]
   // packed U: [tile_n][kt][xi][wc][half][cb] chunks of 1 KiB (64 lanes x float4); group u = HALVES xi + half
@@ -260,59 +214,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
 
   // ---- prologue: patch 0 -> V[0], weight fragments of the first three groups, patch 1 in flight ----
   static_for<36>([&](auto i_) { load_patch1(0, i_); });
-  if constexpr (!PERSIST) {
 #pragma unroll
-    for (int u = 0; u < RING - 1; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
-  }
+  for (int u = 0; u < RING - 1; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
   static_for<6>([&](auto c_) { static_for<6>([&](auto s_) { row_step(c_, s_); }); });
   static_for<6>([&](auto i_) { static_for<6>([&](auto s_) { col_step(0, i_, s_); }); });
-  if constexpr (!PERSIST) {
+  {
     const int k1 = p.nk > 1 ? 1 : 0;
     static_for<36>([&](auto i_) { load_patch1(k1, i_); });
   }
   __syncthreads();
   if constexpr (ABL == 4) stamp1 = __builtin_amdgcn_s_memtime();
 
-  int par = 0;                                   // PERSIST: V stage that holds k-tile 0 of the current block
-  for (;;) {                                     // blocks (one iteration unless PERSIST)
-  if constexpr (PERSIST) {
-    // head of every block, the first one included, so that hardly anything is live across the loop's back edge (loop-carried
-    // patch / weight registers made the register allocator permute and spill): the block's second patch and its first weight
-    // fragments - what the tail of the one-shot prologue requests
-    {
-      // nothing but scalars crosses the loop's back edge: the per-thread constants and this block's patch offsets are
-      // recomputed here from an opaque copy of the thread id
-      int tid_o = threadIdx.x;
-      asm volatile("" : "+v"(tid_o));
-      setup_thread(tid_o);
-      set_in_offsets(t0);
-    }
-    __builtin_amdgcn_sched_barrier(0);           // (the scheduler must not lift these 42 loads into the epilogue above: 96 more
-    static_for<36>([&](auto i_) { load_patch1(1, i_); });         //  live registers there spill the residual rows; nk >= 2 here)
-#pragma unroll
-    for (int u = 0; u < RING - 1; ++u) { load_a1(0, u, 0); load_a1(0, u, 1); }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int i = 0; i < 36; ++i)
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) acc[i][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int fetch_it = p.nk >= 3 ? p.nk - 3 : p.nk - 1;
   for (int kt = 0; kt < p.nk; ++kt) {
-    if constexpr (PERSIST) { if (kt == fetch_it && threadIdx.x == 0) ids[2] = fetch(); }
-    const int cur = PERSIST ? ((par + kt) & 1) : (kt & 1);
+    const int cur = kt & 1;
     const int ktn = kt + 1 < p.nk ? kt + 1 : kt;     // clamped at the end: harmless re-reads keep the loop one block
-    int ktnn = kt + 2 < p.nk ? kt + 2 : kt;
-    if constexpr (PERSIST) {
-      // the input side runs on into the next block: the patch loads of the second-to-last k-tile fetch k-tile 0 of the NEXT block
-      // (which the last k-tile then transforms into the free V stage), those of the last k-tile are switched off (offsets out of
-      // range: the hardware returns zeros without touching memory; their registers die at the epilogue)
-      if (kt == p.nk - 2 && nxt >= 0) { set_in_offsets((nxt / p.tiles_n) * T4); ktnn = 0; }
-      if (kt == p.nk - 1) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) rowoff[r] = INV;
-      }
-    }
+    const int ktnn = kt + 2 < p.nk ? kt + 2 : kt;
     read_v(cur, 0);
     static_for<NG>([&](auto u_) {
       constexpr int u = decltype(u_)::value;
@@ -347,9 +263,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
       __builtin_amdgcn_sched_barrier(0);
     });
     __syncthreads();     // V[cur] fully read, V[cur^1] fully written
-    if constexpr (PERSIST) {                                      // the id thread 0 fetched at the top of this k-tile
-      if (kt == fetch_it) { if (p.nk >= 3) nxt = ids[2]; else nn = ids[2]; }
-    }
   }
 
   if constexpr (ABL == 4) stamp2 = __builtin_amdgcn_s_memtime();
@@ -385,9 +298,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   }
   // ReLU before (2) / after (1) the residual add as an unconditional max: max(x, qNaN) = x keeps "no ReLU" exact
   const float lo2 = p.relu == 2 ? 0.f : __builtin_nanf(""), lo1 = p.relu == 1 ? 0.f : __builtin_nanf("");
-  // (persistent form: ONE set of residual rows, loaded per channel block right after the other block's stores - two sets did
-  //  not fit beside what lives across the block loop and were spilled to scratch, reloaded one store at a time)
-  f32x4 rres[PERSIST ? 1 : 2][16];
+  f32x4 rres[2][16];
   auto load_res = [&](auto cb_) {
     constexpr int cb = decltype(cb_)::value;
     if (p.res_mode == 1) {
@@ -395,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          rres[PERSIST ? 0 : cb][a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 64, 0));
+          rres[cb][a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 64, 0));
     }
   };
   load_res(ic<0>{});
@@ -420,18 +331,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     }
     // the other channel block's residual rows are requested as soon as this block's accumulators are dead, a whole
     // output transform ahead of their use
-    if constexpr (cb == 0 && !PERSIST) { __builtin_amdgcn_sched_barrier(0); load_res(ic<1>{}); __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (cb == 0) { __builtin_amdgcn_sched_barrier(0); load_res(ic<1>{}); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         f32x4 v = out[a * 4 + b] + bv;
         v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
-        if (p.res_mode == 1) v = v + rres[PERSIST ? 0 : cb][a * 4 + b];
+        if (p.res_mode == 1) v = v + rres[cb][a * 4 + b];
         v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yrow[a] + ycol[b], cb * 64, 0);
       }
-    if constexpr (cb == 0 && PERSIST) { __builtin_amdgcn_sched_barrier(0); load_res(ic<1>{}); __builtin_amdgcn_sched_barrier(0); }
   });
   if constexpr (ABL == 4) {
     __builtin_amdgcn_s_waitcnt(0);
@@ -439,27 +349,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     if (p.dbg != nullptr && tid == 0) {
       unsigned long long* o = p.dbg + (long)blockIdx.x * 4;
       o[0] = stamp0; o[1] = stamp1; o[2] = stamp2; o[3] = stamp3;
-    }
-  }
-  if constexpr (!PERSIST) {
-    break;
-  } else {
-    __builtin_amdgcn_sched_barrier(0);
-    if (nxt < 0) break;
-    // ---- next block: its k-tile 0 already sits transformed in V[(par + nk) & 1]; request its second patch and its first weight
-    // fragments (what the tail of the one-shot prologue does), no barrier needed (the epilogue does not touch LDS)
-    par = (par + p.nk) & 1;
-    logical = nxt; nxt = p.nk >= 3 ? -1 : nn;
-    tile_m = logical / p.tiles_n;
-    tile_n = logical - tile_m * p.tiles_n;
-    t0 = tile_m * T4; n0 = tile_n * N4;
-  }
-  }   // blocks
-  if constexpr (PERSIST) {
-    // the last workgroup to leave zeroes the counters: the next launch on this stream finds them clean
-    if (threadIdx.x == 0) {
-      __threadfence();
-      if (atomicAdd(&p.ctr[8], 1u) == gridDim.x - 1) { for (int i = 0; i < 9; ++i) p.ctr[i] = 0u; __threadfence(); }
     }
   }
 }
@@ -527,7 +416,7 @@ extern "C" int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, 
 }
 
 static int wino43_launch(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias, const float* residual,
-                         float* y, glass_stream_t stream, bool body_only, unsigned* counters = nullptr);
+                         float* y, glass_stream_t stream, bool body_only);
 
 extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
                                              const float* bias, const float* residual, float* y, glass_stream_t stream) {
@@ -545,22 +434,8 @@ extern "C" int glass_conv3x3_winograd43_body_nhwc(const glass_conv_desc* d, cons
   return wino43_launch(d, x, u_packed, bias, residual, y, stream, true);
 }
 
-// The same convolution as a PERSISTENT launch: one workgroup per CU takes blocks from per-XCD counters and overlaps every block's
-// prologue with the previous block's last k-tiles (see the kernel).  `counters`: 9 x uint32 in device memory, all zero when the
-// launch starts - the kernel leaves them zero again, so ONE buffer per stream serves every launch on that stream (launches on
-// different streams need different buffers).  flags: 1 = full tile columns only, as glass_conv3x3_winograd43_body_nhwc.  Falls
-// back to the one-shot launch for layers it cannot help (Cin of one k-tile, fewer blocks than CUs).
-extern "C" int glass_conv3x3_winograd43_persistent_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
-                                                        const float* bias, const float* residual, float* y, int flags,
-                                                        unsigned* counters, glass_stream_t stream) {
-  GLASS_CHECK_ARG(counters != nullptr && ((uintptr_t)counters & 3) == 0, "glass_conv3x3_winograd43_persistent_nhwc: counters");
-  GLASS_CHECK_ARG((flags & ~1) == 0, "glass_conv3x3_winograd43_persistent_nhwc: unknown flags 0x%x", flags);
-  GLASS_CHECK_ARG(!(flags & 1) || (d && d->W >= 4), "glass_conv3x3_winograd43_persistent_nhwc: body-only needs W >= 4");
-  return wino43_launch(d, x, u_packed, bias, residual, y, stream, (flags & 1) != 0, counters);
-}
-
 static int wino43_launch(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias, const float* residual,
-                         float* y, glass_stream_t stream, bool body_only, unsigned* counters) {
+                         float* y, glass_stream_t stream, bool body_only) {
   GLASS_CHECK_ARG(d && x && u_packed && y, "glass_conv3x3_winograd43_nhwc: null pointer");
   GLASS_CHECK_ARG(glass_winograd43_supported(d),
                   "glass_conv3x3_winograd43_nhwc: needs 3x3/stride 1/pad 1, Cin%%16==0, Cout%%64==0, unit channel stride, "
@@ -572,7 +447,7 @@ static int wino43_launch(const glass_conv_desc* d, const float* x, const float* 
                   "glass_conv3x3_winograd43_nhwc: pointers must be 16-byte aligned");
   if (d->N == 0) return GLASS_OK;
   WinoParams p;
-  p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y; p.dbg = nullptr; p.ctr = counters;
+  p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y; p.dbg = nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
   p.TH = (d->H + 3) / 4; p.TW = body_only ? d->W / 4 : (d->W + 3) / 4;      // (input / output bounds still use the true W)
   const long nt = (long)d->N * p.TH * p.TW;
@@ -592,26 +467,6 @@ static int wino43_launch(const glass_conv_desc* d, const float* x, const float* 
   p.r_bytes = d->res_mode == 1 ? (unsigned)((long)d->N * d->H * d->W * d->ldr * 4) : 0u;
   const long nblk = (long)p.tiles_m * p.tiles_n;
   GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv3x3_winograd43_nhwc: bad grid");
-  static const int n_cu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
-  if (counters != nullptr && p.nk >= 2 && nblk > n_cu) {
-    // persistent form: one workgroup per CU, dynamic block list, prologue of block n + 1 inside the last k-tiles of block n
-    auto pk = wide ? conv3x3_wino43_f32<0, 1, 4, 32, true> : conv3x3_wino43_f32<0, 2, 2, 16, true>;
-    static int prc_w = -1, prc_n = -1;
-    int& prc = wide ? prc_w : prc_n;
-    if (prc == -1)
-      prc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, WINO43_LDS_BYTES + 16);
-    if (prc != 0) {
-      glass_set_error("glass_conv3x3_winograd43_persistent_nhwc: cannot reserve %d bytes of LDS (hip error %d)", WINO43_LDS_BYTES + 16, prc);
-      return GLASS_EHIP;
-    }
-    hipLaunchKernelGGL(pk, dim3((unsigned)n_cu), dim3(256), WINO43_LDS_BYTES + 16, (hipStream_t)stream, p);
-    GLASS_CHECK_LAUNCH("glass_conv3x3_winograd43_persistent_nhwc");
-    return GLASS_OK;
-  }
   static const int abl = getenv("GLASS_W43_ABL") ? atoi(getenv("GLASS_W43_ABL")) : 0;      // timing ablations (wrong results)
   // (the ablation instantiations 1..3 are compiled only with -DGLASS_W43_ABLATIONS: they triple the build time of this file)
   auto kern = !wide ? (abl == 4 ? conv3x3_wino43_f32<4, 2, 2, 16> : conv3x3_wino43_f32<0, 2, 2, 16>)

@@ -102,14 +102,12 @@ class Routing:
       ragged      maps of width 4 k + 1 on the F(4x4) kernel: full tile columns there + the last pixel column as a strip
                   convolution (GLASS_W43_RAGGED=0: a whole extra tile column, as in rounds 2-3)
       pooled_fusion  P2P3Fusion's two 1x1 convolutions AFTER the recognizer pooler (on the pooled bins) instead of on the whole
-                  p2 / p3 maps - RoIAlign and the fusion are both linear (GLASS_POOLED_FUSION=0: whole-map fusion, then pool)
-      persist     the F(4x4) kernel as a persistent launch (one workgroup per CU, dynamic block list, every block's prologue inside
-                  the previous block's last k-tiles; GLASS_W43_PERSIST=1)"""
-    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion", "persist")
+                  p2 / p3 maps - RoIAlign and the fusion are both linear (GLASS_POOLED_FUSION=0: whole-map fusion, then pool)"""
+    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion")
 
     def __init__(self, precision: Optional[str] = None, winograd: Optional[bool] = None, f43: Optional[bool] = None, pw=None,
                  h16: Optional[bool] = None, local_stem: Optional[bool] = None, stem: Optional[bool] = None,
-                 ragged: Optional[bool] = None, pooled_fusion: Optional[bool] = None, persist: Optional[bool] = None):
+                 ragged: Optional[bool] = None, pooled_fusion: Optional[bool] = None):
         e = os.environ.get
         self.precision = precision or e("GLASS_CONV_PRECISION", "fp32")
         if self.precision not in _PRECISIONS:
@@ -122,7 +120,6 @@ class Routing:
         self.stem = (e("GLASS_BACKBONE_STEM", "1") != "0") if stem is None else bool(stem)
         self.ragged = (e("GLASS_W43_RAGGED", "1") != "0") if ragged is None else bool(ragged)
         self.pooled_fusion = (e("GLASS_POOLED_FUSION", "1") != "0") if pooled_fusion is None else bool(pooled_fusion)
-        self.persist = (e("GLASS_W43_PERSIST", "0") != "0") if persist is None else bool(persist)
 
     def replace(self, **kw) -> "Routing":
         r = Routing.__new__(Routing)
@@ -479,27 +476,16 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
               ldx == Cin and res_mode in (0, 1) and x.numel() > 0 and (not isinstance(w, ConvWeight) or "col1" in w.packs))
     f43 = winograd == "f43" or (winograd is None and rt.f43 and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin, ragged))
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
-        def w43(body_only: bool) -> torch.Tensor:
-            """the F(4x4,3x3) kernel: one-shot launch (one block per launch slot) or persistent (rt.persist)"""
-            u = _packed(w, wt, True)
-            if not rt.persist:
-                return launch("glass_conv3x3_winograd43_body_nhwc" if body_only else "glass_conv3x3_winograd43_nhwc", "winograd43", x, u)
-            _TLS.last_path = "winograd43"
-            check(lib().glass_conv3x3_winograd43_persistent_nhwc(
-                ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(u, "w")), c_void_p(_dev(bias, "bias") if bias is not None else None),
-                c_void_p(_dev(residual, "residual") if residual is not None else None), c_void_p(_dev(out, "out")), int(body_only),
-                c_void_p(_dev(_persist_counters(x.device))), c_void_p(stream_handle())), "glass_conv3x3_winograd43_persistent_nhwc")
-            return out
         if ragged:
             # width 4 k + 1 (the local extractor's 16 x 33 maps): the F(4x4) kernel on the k full tile columns - 32 instead of
             # 36 tiles per 16 x 33 map, and e.g. 1024 instead of 1152 workgroups = 4 instead of 4.5 rounds on 256 CUs - and
             # the last pixel column as a KH = 3, KW = 1 convolution over the last two input columns seen as 2*Cin channels
             # (x, y and the residual re-viewed as [N,H,1,W*ld] rows with a channel offset; no copy)
-            w43(True)
+            launch("glass_conv3x3_winograd43_body_nhwc", "winograd43", x, _packed(w, wt, True))
             _last_column_strip(x, _packed(w, wt, "col1"), bias, residual, out, d, out_coff)
             _TLS.last_path = "winograd43r"          # (bench / profiling: F(4x4) body + last-column strip)
             return out
-        return w43(False)
+        return launch("glass_conv3x3_winograd43_nhwc", "winograd43", x, _packed(w, wt, True))
     if winograd == "f43":
         raise GlassLibraryError("winograd='f43' but glass_winograd43_supported() rejects this layer")
     if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
@@ -508,21 +494,6 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     if winograd:
         raise GlassLibraryError("winograd=True but glass_winograd_supported() rejects this layer")
     return launch("glass_conv2d_nhwc", "direct", x, wt)
-
-
-_PERSIST_CTR = {}          # (device index, stream handle) -> 9 zeroed uint32 counters of the persistent F(4x4) launches on that stream
-
-
-def _persist_counters(device) -> torch.Tensor:
-    """the block counters of persistent launches on the CURRENT stream: zero at creation, and every launch leaves them zero, so
-    one buffer per stream is enough (launches on a stream are ordered; different streams get different buffers)"""
-    key = (device.index, stream_handle())
-    t = _PERSIST_CTR.get(key)
-    if t is None:
-        t = torch.zeros((16,), dtype=torch.int32, device=device)
-        torch.cuda.current_stream().synchronize()       # once per stream: the fill ran on torch's current stream = this one, but be explicit
-        _PERSIST_CTR[key] = t
-    return t
 
 
 def _last_column_strip(x: torch.Tensor, wcol: torch.Tensor, bias, residual, out: torch.Tensor, d: ConvDesc, out_coff: int) -> None:

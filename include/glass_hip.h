@@ -141,14 +141,6 @@ int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, cons
  * channels = (kw, cin), see glass_amd/ops/native.py).  Same descriptor (the TRUE H, W), epilogue and errors.          */
 int glass_conv3x3_winograd43_body_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                        const float* residual, float* y, glass_stream_t stream);
-/* the same convolution(s) as a PERSISTENT launch: one workgroup per CU takes blocks from per-XCD counters, and the prologue of
- * every block but a workgroup's first (first input patch from HBM, its transform) runs inside the previous block's last two
- * k-tiles.  Same results bit for bit (the same blocks compute the same outputs in the same order of operations).
- * `counters`: 9 x uint32 of device memory, all zero at launch; the kernel leaves them zero, so one buffer per STREAM serves
- * every launch on it.  flags: 1 = full tile columns only (glass_conv3x3_winograd43_body_nhwc).  Layers it cannot help (one
- * k-tile, fewer blocks than CUs) take the one-shot launch.                                                                 */
-int glass_conv3x3_winograd43_persistent_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
-                                             const float* residual, float* y, int flags, unsigned* counters, glass_stream_t stream);
 
 /* 1x1 convolution as a weight-streaming GEMM (csrc/pointwise.hip): the bottleneck / lateral / shortcut 1x1 layers with
  * Cin % 32 == 0 and Cout % 128 == 0, any square stride, pad 0.  Same descriptor, epilogue semantics (bias, ReLU before /
