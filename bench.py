@@ -224,6 +224,58 @@ def cpu_baseline(cfg, sd, side, rois):
                                       f"median {med1:.2f} s (runs {', '.join(f'{t:.2f}' for t in ts1)} s)"}}
 
 
+def dry_run(args, rank, world, dist) -> None:
+    """GLASS_BENCH_DRYRUN=1: the N-rank plumbing of this script WITHOUT a GPU or a model (the `-m "not gpu"` tests run it with
+    world 2): the same launch path (self-launched ranks or torchrun), process group (gloo), `run_pipelined` schedule with a host
+    read-back per step, ONE all_gather of fixed-size word records per step inside the timed region, max-over-ranks timing, `comm`
+    block and line assertions as the real bench - only the step's records are synthetic.  Prints a line marked as a dry run; it is
+    not a measurement."""
+    from glass_amd.distributed import all_gather_records, words_record_size
+    from glass_amd.utils.pipeline import ReadBack, run_pipelined
+    B, max_det, steps_txt = args.batch, 100, 26
+    width = words_record_size(max_det, steps_txt)
+
+    def step_g(i):
+        rec = torch.zeros((B, width))
+        rec[:, 0] = float((rank * 7 + i) % 5)                       # word counts: differ by rank and step
+        (counts,) = yield ReadBack(rec[:, 0].clone())                # a host read-back, like the real step's three
+        assert counts.shape == (B,)
+        return all_gather_records(rec, rows=B)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    run_pipelined([(lambda i=i: step_g(i)) for i in range(args.warmup)], depth=args.pipeline, device="cpu")
+    barrier()
+    t0 = time.perf_counter()
+    res = run_pipelined([(lambda i=i: step_g(100 + i)) for i in range(args.steps)], depth=args.pipeline, device="cpu")
+    barrier()
+    dt = time.perf_counter() - t0
+    last = res[-1]
+    assert last.dim() == 3 and tuple(last.shape) == (world, B, width), (tuple(last.shape), world, B, width)
+    for r in range(world):                                          # every rank holds every rank's records of the LAST step
+        assert float(last[r, 0, 0]) == float((r * 7 + 100 + args.steps - 1) % 5), (r, float(last[r, 0, 0]))
+    comm = {"world_size": 1, "backend": None}
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        per_rank = torch.empty((world,), dtype=torch.float64)
+        dist.all_gather_into_tensor(per_rank, t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                "per_rank_ms_per_step": [round(v / args.steps * 1e3, 3) for v in per_rank.tolist()],
+                "gathered_records_shape": list(last.shape), "gathered_records_expected": world * B}
+        dt = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        line = {"metric": "DRY RUN of the N-rank plumbing (no GPU, no model): not a measurement", "value": world * B * args.steps / dt,
+                "unit": "synthetic records/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3, "data": "dry-run", "comm": comm}
+        assert line["n_gpus"] == args.gpus == comm["world_size"]
+        print(json.dumps(line), flush=True)
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (reference tools/eval_glass.py:199-206
     `launch(main, num_gpus, ...)`), each a re-exec of this command with the torch.distributed.run environment, and return
@@ -231,6 +283,8 @@ def self_launch(args) -> int:
     GLASS_BENCH_BACKEND=gloo lifts that check to exercise the N-rank plumbing on a 1-GPU box."""
     from glass_amd.distributed import launch_local_ranks
     backend = os.environ.get("GLASS_BENCH_BACKEND", "nccl")
+    if os.environ.get("GLASS_BENCH_DRYRUN"):                      # plumbing only: no GPU needed, gloo
+        return launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU fallback for the product path)", file=sys.stderr)
         return 2
@@ -253,6 +307,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+    if os.environ.get("GLASS_BENCH_DRYRUN"):
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)                                         # gloo's connection chatter goes to stderr
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
+        return dry_run(args, rank, world, dist)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     ndev = torch.cuda.device_count()

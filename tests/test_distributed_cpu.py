@@ -281,3 +281,31 @@ def test_oversized_shard_with_rows_raises_on_every_rank_instead_of_hanging():
         p.join(120)
         assert p.exitcode == 0
     assert got == [(0, "poisoned"), (1, "local")]
+
+
+def _run_bench(extra_env, *argv, timeout=600):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_dry_run_two_self_launched_ranks():
+    """bench.py's OWN N-rank path on CPU (GLASS_BENCH_DRYRUN=1: no GPU, no model, synthetic records): `python bench.py --gpus 2`
+    launches two ranks itself, they form a gloo group, run the pipelined schedule with one all_gather of word records per step and
+    rank 0 prints ONE JSON line with n_gpus == 2 == comm.world_size and a [2, B, record] gather - the plumbing the 8-GPU run uses."""
+    import json
+    p = _run_bench({"GLASS_BENCH_DRYRUN": "1"}, "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "3")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["comm"]["world_size"] == 2 and d["comm"]["backend"] == "gloo" and d["data"] == "dry-run"
+    assert d["comm"]["gathered_records_shape"][:2] == [2, 3] and d["comm"]["gathered_records_expected"] == 6
+    assert len(d["comm"]["per_rank_ms_per_step"]) == 2
+    # the same through torchrun's environment contract (the driver's N > 1 launch): a rank joins the world it is given
+    p = _run_bench({"GLASS_BENCH_DRYRUN": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "1", "--steps", "2", "--warmup", "0")
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # ... and refuses a world that contradicts --gpus
+    p = _run_bench({"GLASS_BENCH_DRYRUN": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--steps", "2")
+    assert p.returncode != 0 and p.stdout.strip() == ""
