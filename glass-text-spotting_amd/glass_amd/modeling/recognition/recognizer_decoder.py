@@ -1,4 +1,5 @@
-"""Attention decoder (`ASTER_V2` -> `AttentionRecognitionHead.sample`) as one persistent HIP kernel.
+"""Attention decoder (`ASTER_V2` -> `AttentionRecognitionHead.sample`) behind ONE ABI call (glass_attention_decode: two kernels per
+decoding step spread over the chip, arg-max feedback on the device, the per-image early break applied by a mask kernel afterwards).
 
 Mirrors reference glass/modeling/recognition/recognizer_decoder.py:65-93 and
 prediction_aster.py:63-99 (greedy sampling, eos index 0, pre-zeroed [R,26,97] output with
