@@ -18,7 +18,7 @@
 //     channels) or the 128- / 64-pixel fractions of those; <= 128 accumulator registers, TWO workgroups per CU.
 // k-tile order is (channel block, tap) with the tap fastest, so the nine shifted reads of a channel block hit L2 / L1.
 // Results: fp16?(act(sum over fp16(x) fp16(w) in fp32 + bias [+ residual])) - the same arithmetic as
-// glass_conv2d_nhwc_h16 up to fp32 summation order (tests/test_gpu_ops.py compares the two and the fp64 reference).
+// glass_conv2d_nhwc_h16 up to fp32 summation order (tests/test_gpu_f_ops.py compares the two and the fp64 reference).
 #include "wino_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -4,7 +4,7 @@
 // issues 36 per 4x4 tile = 2.25 (1.78x fewer again, 4x fewer than the direct convolution), reads 36 instead of 64
 // input values per 16 outputs and streams 2.25x the weight bytes.  fp32 accuracy is the price of the larger
 // transform: with the usual points (0, +-1, +-2) the error is 1.5e-5 of the output range on a 256-channel layer;
-// this kernel uses the points (0, 1, -1, 1/2, -2, inf), measured at 4.7e-6 (fp64 reference; tests/test_gpu_ops.py
+// this kernel uses the points (0, 1, -1, 1/2, -2, inf), measured at 4.7e-6 (fp64 reference; tests/test_gpu_f_ops.py
 // holds the kernel to 2e-5 of the range), at the cost of a transform without the even/odd symmetry (16 instead of
 // ~12 operations per 6-point transform).
 //

@@ -99,7 +99,7 @@ int glass_conv2d_nhwc_h16_packed(const glass_conv_desc* d, const void* x, const 
 /* Winograd F(2x2,3x3) form of the same operator for the 3x3 / stride 1 / pad 1 layers (FPN output convs,
  * RPN head conv, every 3x3 of the ResNet trunk and of the local extractor's BasicBlocks, fusion output
  * conv): 2.25x fewer fp32 MFMA multiplies, results equal to glass_conv2d_nhwc to fp32 rounding
- * (|diff| <~ 1e-5 of the output scale; tests/test_gpu_ops.py).  Same descriptor, epilogue semantics and
+ * (|diff| <~ 1e-5 of the output scale; tests/test_gpu_f_ops.py).  Same descriptor, epilogue semantics and
  * error behaviour as glass_conv2d_nhwc; `u_packed` replaces `w`:
  *   glass_winograd_supported(d)            1 if the descriptor can take this path (3x3 s1 p1, Cin % 16 == 0,
  *                                          Cout % 64 == 0, y_cstride == 1, ldy/y_coff % 4 == 0, res_mode 0/1,
@@ -125,7 +125,7 @@ int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float* x, const 
  * 4x fewer than the direct convolution, for the layers with Cout % 128 == 0 and Cin % 32 == 0 (the 128/256/512
  * channel 3x3 layers: FPN outputs, RPN head, trunk, local extractor layer2..4, mask head).  Transform points
  * (0, 1, -1, 1/2, -2, inf): results equal glass_conv2d_nhwc to <= 2e-5 of the output range (fp64 reference;
- * tests/test_gpu_ops.py), still two orders of magnitude inside the path's 1e-3 bar.  Same descriptor, epilogue
+ * tests/test_gpu_f_ops.py), still two orders of magnitude inside the path's 1e-3 bar.  Same descriptor, epilogue
  * semantics and error behaviour as glass_conv3x3_winograd_nhwc; its own packed weight layout (36 * Cout * Cin
  * floats).  glass_winograd43_supported additionally wants input, output and residual spans < 1 GiB each (split
  * 32-bit offsets) - callers fall back to the F(2x2) entry.                                                        */
@@ -158,7 +158,7 @@ int glass_conv1x1_pointwise_nhwc(const glass_conv_desc* d, const float* x, const
  * conv0_1 (3x3, 3->16) + BN + ReLU, conv0_2 (3x3, 16->32) + BN + ReLU, maxpool1 2x2 in ONE kernel - the two intermediate
  * maps stay in LDS.  x [R,H,W,4] NHWC4 crops, w1 [16][3][3][4] / b1 [16], w2 [32][3][3][16] / b2 [32] (BatchNorm folded),
  * y [R,H/2,W/2,32]; fp32.  Same results as the three separate entries up to fp32 summation order
- * (tests/test_gpu_ops.py).  glass_local_stem_supported: H and W positive multiples of 32 (128 x 128 crops in every
+ * (tests/test_gpu_f_ops.py).  glass_local_stem_supported: H and W positive multiples of 32 (128 x 128 crops in every
  * reference config) - otherwise callers use the separate entries.                                                   */
 int glass_local_stem_supported(int H, int W);
 int glass_local_stem_fused(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y,
