@@ -241,17 +241,47 @@ def rank_env(rank: int, world_size: int, port: int, base: Optional[Dict[str, str
     return env
 
 
+def _die_with_parent() -> None:
+    """child side (between fork and exec): SIGKILL this rank when the launcher dies, however it dies (Linux PR_SET_PDEATHSIG) -
+    the ranks sit in their own sessions, so a signal aimed at the launcher's process group would not reach them and they would
+    keep their GPUs"""
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)       # 1 = PR_SET_PDEATHSIG
+    except Exception:                                                                          # noqa: BLE001 - best effort
+        pass
+
+
+class _Terminated(BaseException):
+    pass
+
+
 def launch_local_ranks(argv: Sequence[str], world_size: int, port: Optional[int] = None, base_env: Optional[Dict[str, str]] = None,
                        poll_s: float = 0.05, grace_s: float = 5.0) -> int:
     """Start `argv` once per rank (own session each, stdio inherited), wait for all of them; the first non-zero exit code
     terminates the remaining ranks (SIGTERM to exactly the process groups started here, SIGKILL after `grace_s`) and is
-    returned - a rank that died must not leave the others waiting in a collective.  0 = every rank exited 0."""
+    returned - a rank that died must not leave the others waiting in a collective.  0 = every rank exited 0.
+    The ranks never outlive the launcher: SIGTERM / SIGINT / SIGHUP to the launcher stop them the same way (and return
+    128 + signal), and a launcher that is killed outright takes them along (`_die_with_parent`)."""
+    import signal
+    import threading
     if world_size < 1:
         raise ValueError("world_size must be >= 1")
     port = free_port() if port is None else int(port)
-    procs = [subprocess.Popen(list(argv), env=rank_env(r, world_size, port, base_env), start_new_session=True)
+    procs = [subprocess.Popen(list(argv), env=rank_env(r, world_size, port, base_env), start_new_session=True,
+                              preexec_fn=_die_with_parent)
              for r in range(world_size)]
     rc = 0
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        def on_signal(signum, _frame):
+            raise _Terminated(signum)
+        for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            try:
+                old_handlers[sg] = signal.signal(sg, on_signal)
+            except (OSError, ValueError):
+                pass
     try:
         live = set(range(world_size))
         while live and rc == 0:
@@ -265,8 +295,12 @@ def launch_local_ranks(argv: Sequence[str], world_size: int, port: Optional[int]
                         break
             if live and rc == 0:
                 time.sleep(poll_s)
+    except _Terminated as e:
+        rc = 128 + int(e.args[0])
+        print(f"[launch_local_ranks] signal {int(e.args[0])}: stopping the ranks", file=sys.stderr)
     finally:
-        import signal
+        for sg, h in old_handlers.items():
+            signal.signal(sg, signal.SIG_IGN)                        # no second interruption while the ranks are being stopped
         for sig, wait in ((signal.SIGTERM, grace_s), (signal.SIGKILL, grace_s)):
             left = [p for p in procs if p.poll() is None]
             if not left:
@@ -279,4 +313,6 @@ def launch_local_ranks(argv: Sequence[str], world_size: int, port: Optional[int]
             t_end = time.time() + wait
             while time.time() < t_end and any(p.poll() is None for p in left):
                 time.sleep(poll_s)
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     return rc

@@ -309,3 +309,45 @@ def test_bench_dry_run_two_self_launched_ranks():
     # ... and refuses a world that contradicts --gpus
     p = _run_bench({"GLASS_BENCH_DRYRUN": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2", "--steps", "2")
     assert p.returncode != 0 and p.stdout.strip() == ""
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    # a zombie still answers kill(0): look at its state
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_ranks_never_outlive_the_launcher(tmp_path):
+    """the ranks sit in their own sessions (so that the launcher can stop exactly them), which also means a signal aimed at the
+    launcher does not reach them: SIGTERM to the launcher must stop them (handler -> the same shutdown path), and a launcher that
+    is SIGKILLed takes them along (PR_SET_PDEATHSIG) - a timed-out bench must not leave ranks holding the GPUs."""
+    import signal
+    import subprocess
+    import time
+    child = "import os, sys, time; open(os.path.join(sys.argv[1], 'pid' + os.environ['RANK']), 'w').write(str(os.getpid())); time.sleep(120)"
+    prog = (f"import sys; sys.path.insert(0, {os.path.join(ROOT, 'glass-text-spotting_amd')!r})\n"
+            f"from glass_amd.distributed import launch_local_ranks\n"
+            f"sys.exit(launch_local_ranks([sys.executable, '-c', {child!r}, sys.argv[1]], 2, grace_s=3.0))\n")
+    for how, sig in (("term", signal.SIGTERM), ("kill", signal.SIGKILL)):
+        d = tmp_path / how
+        d.mkdir()
+        lp = subprocess.Popen([sys.executable, "-c", prog, str(d)])
+        t_end = time.time() + 60
+        while time.time() < t_end and not all((d / f"pid{r}").exists() and (d / f"pid{r}").read_text() for r in range(2)):
+            time.sleep(0.1)
+        pids = [int((d / f"pid{r}").read_text()) for r in range(2)]
+        assert all(_alive(p) for p in pids)
+        lp.send_signal(sig)
+        rc = lp.wait(timeout=30)
+        assert rc == (128 + signal.SIGTERM if how == "term" else -signal.SIGKILL), rc
+        t_end = time.time() + 15
+        while time.time() < t_end and any(_alive(p) for p in pids):
+            time.sleep(0.1)
+        assert not any(_alive(p) for p in pids), f"ranks survived a launcher that got {how}"
