@@ -10,6 +10,14 @@
 // round trip per iteration), i.e. 6x the whole network; here it is one workgroup per image, everything in
 // LDS (<= 128 boxes), no host involvement until the final read of the compact results.
 //
+// Latency (round 4): the merge loop is a chain of small dependent phases, so what matters is the length of ONE thread's
+// work in each.  The dynamically indexed point lists of the rotated IoU (24 points) and of the minimum-area rectangle
+// (32 double points) used to live in private memory = scratch, a memory round trip per access: 25-30 us per phase,
+// ~85 us per merge iteration, 0.4-1.0 ms per launch on the bench's 32 overlapping words per image and 10 ms on 128
+// dense ones.  They are LDS columns now (one per thread, 64 KB shared by the phases), the candidate filter is one box
+// per thread instead of a loop of thread 0, and the per-(box, step) argmax over the characters runs before this kernel
+// on the whole chip (text_argmax_kernel: a wavefront per row) instead of at its end on one CU.
+//
 // Semantics kept on purpose: the merge loop works on a SNAPSHOT of the boxes, writes merged boxes back
 // first through all first indices then through all second indices of the valid pairs in row-major pair
 // order ("last pair wins", the CPU result of the reference's repeated-index assignment), re-orders the
@@ -19,10 +27,11 @@
 
 constexpr int PP_KMAX = 128;
 constexpr int PP_THREADS = 256;
+constexpr int PP_WORK_BYTES = 65536;     // max(24 Pt x 256 threads, 32 DPt x 128 boxes)
 
 struct PPParams {
-  const float* boxes; const float* scores; const int* counts; const float* text; const float* scale_xy;
-  int N, K, T, C;
+  const float* boxes; const float* scores; const int* counts; const int* text_arg; const float* text_max; const float* scale_xy;
+  int N, K, T;
   float min_box_dim, valid_score, detect_thr, merge_ioa, height_ratio, max_angle_diff, minimal_ioa, text_thr;
   int stop_index, do_text;
   float* out_boxes; float* out_scores; float* out_poly; int* out_src; int* out_char; float* out_text_score;
@@ -35,8 +44,19 @@ struct PPParams {
 struct DPt { double x, y; };
 __device__ inline double dcross(DPt o, DPt a, DPt b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); }
 
-__device__ void min_area_rect8(const float* pts /*[8][2]*/, double& cx, double& cy, double& w, double& h, double& ang) {
-  DPt p[8];
+// per-thread point lists in LDS: element i of thread t at base[i * stride + t] (conflict-free across a wavefront)
+struct LdsPts {
+  Pt* base;
+  __device__ __forceinline__ Pt& operator[](int i) const { return base[i * PP_THREADS]; }
+};
+struct LdsDPts {
+  DPt* base;
+  __device__ __forceinline__ DPt& operator[](int i) const { return base[i * PP_KMAX]; }
+};
+
+// `A`: 32 points of storage (sorted points 0..7, hull 8..23, upper chain 24..31)
+__device__ void min_area_rect8(const float* pts /*[8][2]*/, LdsDPts A, double& cx, double& cy, double& w, double& h, double& ang) {
+  const LdsDPts p{A.base}, hull{A.base + 8 * PP_KMAX}, upper{A.base + 24 * PP_KMAX};
   int n = 8;
   for (int i = 0; i < 8; ++i) { p[i].x = (double)pts[2 * i]; p[i].y = (double)pts[2 * i + 1]; }
   // insertion sort by (x, y), then drop exact duplicates
@@ -50,28 +70,29 @@ __device__ void min_area_rect8(const float* pts /*[8][2]*/, double& cx, double& 
   for (int i = 0; i < n; ++i)
     if (m == 0 || p[i].x != p[m - 1].x || p[i].y != p[m - 1].y) p[m++] = p[i];
   n = m;
-  DPt hull[16];
   int hn = 0;
   if (n <= 2) {
     for (int i = 0; i < n; ++i) hull[hn++] = p[i];
   } else {
-    DPt lower[8], upper[8];
-    int nl = 0, nu = 0;
+    int nl = 0, nu = 0;                           // (the lower chain is built in place at the head of `hull`)
     for (int i = 0; i < n; ++i) {
-      while (nl >= 2 && dcross(lower[nl - 2], lower[nl - 1], p[i]) <= 0) --nl;
-      lower[nl++] = p[i];
+      const DPt pi = p[i];
+      while (nl >= 2 && dcross(hull[nl - 2], hull[nl - 1], pi) <= 0) --nl;
+      hull[nl++] = pi;
     }
     for (int i = n - 1; i >= 0; --i) {
-      while (nu >= 2 && dcross(upper[nu - 2], upper[nu - 1], p[i]) <= 0) --nu;
-      upper[nu++] = p[i];
+      const DPt pi = p[i];
+      while (nu >= 2 && dcross(upper[nu - 2], upper[nu - 1], pi) <= 0) --nu;
+      upper[nu++] = pi;
     }
-    for (int i = 0; i < nl - 1; ++i) hull[hn++] = lower[i];
+    hn = nl - 1;
     for (int i = 0; i < nu - 1; ++i) hull[hn++] = upper[i];
   }
-  if (hn == 1) { cx = hull[0].x; cy = hull[0].y; w = 0; h = 0; ang = 0; return; }
+  if (hn == 1) { const DPt h0 = hull[0]; cx = h0.x; cy = h0.y; w = 0; h = 0; ang = 0; return; }
   if (hn == 2) {
-    const double dx = hull[1].x - hull[0].x, dy = hull[1].y - hull[0].y;
-    cx = (hull[0].x + hull[1].x) / 2; cy = (hull[0].y + hull[1].y) / 2;
+    const DPt h0 = hull[0], h1 = hull[1];
+    const double dx = h1.x - h0.x, dy = h1.y - h0.y;
+    cx = (h0.x + h1.x) / 2; cy = (h0.y + h1.y) / 2;
     w = hypot(dx, dy); h = 0; ang = atan2(dy, dx) * 57.29577951308232;
     return;
   }
@@ -84,7 +105,8 @@ __device__ void min_area_rect8(const float* pts /*[8][2]*/, double& cx, double& 
     const double ux = ex / nrm, uy = ey / nrm, vx = -uy, vy = ux;
     double pumin = 1e300, pumax = -1e300, pvmin = 1e300, pvmax = -1e300;
     for (int k = 0; k < hn; ++k) {
-      const double pu = hull[k].x * ux + hull[k].y * uy, pv = hull[k].x * vx + hull[k].y * vy;
+      const DPt hk = hull[k];
+      const double pu = hk.x * ux + hk.y * uy, pv = hk.x * vx + hk.y * vy;
       pumin = fmin(pumin, pu); pumax = fmax(pumax, pu); pvmin = fmin(pvmin, pv); pvmax = fmax(pvmax, pv);
     }
     const double ww = pumax - pumin, hh = pvmax - pvmin;
@@ -122,14 +144,14 @@ __device__ inline void box_polygon(const float* b, float* poly /*[4][2]*/) {
 }
 
 // _merge_rotated_boxes (:187-216) + polygons_to_rotated_boxes (:253-286) for one pair
-__device__ void merge_pair(const float* b1, const float* b2, float s1, float s2, float* out) {
+__device__ void merge_pair(const float* b1, const float* b2, float s1, float s2, LdsDPts A, float* out) {
   float pts[16];
   box_polygon(b1, pts);
   box_polygon(b2, pts + 8);
   const float a1 = b1[4] * 3.14159265358979323846f / 180.f, a2 = b2[4] * 3.14159265358979323846f / 180.f;
   const double orient = (double)(s1 >= s2 ? a1 : a2);          // radians (reference quirk)
   double cx, cy, w, h, ang;
-  min_area_rect8(pts, cx, cy, w, h, ang);
+  min_area_rect8(pts, A, cx, cy, w, h, ang);
   double angle = 90.0 - ang;
   double diff = pymod((orient - angle) + 180.0, 360.0) - 180.0;
   double width, height;
@@ -166,18 +188,34 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
   __shared__ int src[PP_KMAX], tmpi[PP_KMAX], order[PP_KMAX];
   __shared__ float ioa[PP_KMAX][PP_KMAX + 1];      // IoA (merge) / IoU (NMS) matrix
   __shared__ unsigned char flag[PP_KMAX];
-  __shared__ int s_n, s_any;
+  __shared__ int s_n, s_any, s_wave_cnt[2];
+  // the threads' point lists (rotated IoU: 24 points per thread; merge: 32 double points per box); the phases that use the
+  // two views are separated by barriers
+  __shared__ __attribute__((aligned(16))) unsigned char work[PP_WORK_BYTES];
   const int n_img = blockIdx.x, tid = threadIdx.x;
   const int cnt = min(p.counts[n_img], min(p.K, PP_KMAX));
   const float* gb = p.boxes + (long)n_img * p.K * 5;
   const float* gs = p.scores + (long)n_img * p.K;
+  LdsPts iou_pts{reinterpret_cast<Pt*>(work) + tid};
+#ifdef GLASS_PP_STAMPS      // phase clocks of every workgroup, printed at its end (scripts/build_variant_lib.sh ppst -DGLASS_PP_STAMPS)
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime(), tstart = tlast;
+  int iters = 0;
+#define PP_STAMP(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); st[k] += tn - tlast; tlast = tn; }
+#else
+#define PP_STAMP(k)
+#endif
 
-  // ---- load (+ optional RotatedBoxes.scale of the runner's un-scaling), filter_small_boxes, score >= valid
-  if (tid == 0) {
-    int n = 0;
-    const float sx = p.scale_xy ? p.scale_xy[2 * n_img] : 1.f, sy = p.scale_xy ? p.scale_xy[2 * n_img + 1] : 1.f;
-    for (int j = 0; j < cnt; ++j) {
-      float b[5] = {gb[5 * j], gb[5 * j + 1], gb[5 * j + 2], gb[5 * j + 3], gb[5 * j + 4]};
+  // ---- load (+ optional RotatedBoxes.scale of the runner's un-scaling), filter_small_boxes, score >= valid:
+  // candidate j on thread j (wavefronts 0 and 1), survivors compacted in order through the two ballots
+  {
+    const int j = tid;
+    float b[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, sj = 0.f;
+    bool keep = false;
+    if (j < cnt) {
+      const float sx = p.scale_xy ? p.scale_xy[2 * n_img] : 1.f, sy = p.scale_xy ? p.scale_xy[2 * n_img + 1] : 1.f;
+#pragma unroll
+      for (int e = 0; e < 5; ++e) b[e] = gb[5 * j + e];
+      sj = gs[j];
       if (p.scale_xy && (sx != 1.f || sy != 1.f)) {     // GlassRunner un-scales only when the ratio != 1
         b[0] *= sx; b[1] *= sy;
         const float theta = b[4] * 3.14159265358979323846f / 180.0f;
@@ -187,16 +225,23 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
         b[3] *= sqrtf((sx * sn) * (sx * sn) + (sy * cs) * (sy * cs));
         b[4] = atan2f(sx * sn, sy * cs) * 180.0f / 3.14159265358979323846f;
       }
-      if (fminf(b[2], b[3]) >= p.min_box_dim && gs[j] >= p.valid_score) {
-        for (int e = 0; e < 5; ++e) bx[n][e] = b[e];
-        sc[n] = gs[j];
-        src[n] = j;
-        ++n;
-      }
+      keep = fminf(b[2], b[3]) >= p.min_box_dim && sj >= p.valid_score;
     }
-    s_n = n;
+    const unsigned long long kept = __ballot(keep);                 // (of this wavefront)
+    if (tid < PP_KMAX && (tid & 63) == 0) s_wave_cnt[tid >> 6] = __popcll(kept);
+    __syncthreads();
+    if (keep) {
+      const int lane = tid & 63;
+      const int d = (tid >= 64 ? s_wave_cnt[0] : 0) + __popcll(kept & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+#pragma unroll
+      for (int e = 0; e < 5; ++e) bx[d][e] = b[e];
+      sc[d] = sj;
+      src[d] = j;
+    }
+    if (tid == 0) s_n = s_wave_cnt[0] + s_wave_cnt[1];
   }
   __syncthreads();
+  PP_STAMP(0)
 
   // ---- merge_intersecting_boxes
   for (int iter = 0; iter < 4 * PP_KMAX; ++iter) {
@@ -212,8 +257,8 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
       pp_pair(q, n, i, j);
       float v = 0.f;
       if (!pp_far_apart(snap[i], snap[j])) {
-        const float iou = rotated_iou(make_rbox(snap[i][0], snap[i][1], snap[i][2], snap[i][3], snap[i][4]),
-                                      make_rbox(snap[j][0], snap[j][1], snap[j][2], snap[j][3], snap[j][4]));
+        const float iou = rotated_iou_in(make_rbox(snap[i][0], snap[i][1], snap[i][2], snap[i][3], snap[i][4]),
+                                         make_rbox(snap[j][0], snap[j][1], snap[j][2], snap[j][3], snap[j][4]), iou_pts);
         const float a1 = snap[i][2] * snap[i][3], a2 = snap[j][2] * snap[j][3];
         const float inter = (a1 + a2) * iou / (1.f + iou);
         v = inter / fminf(a1, a2);
@@ -221,6 +266,7 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
       ioa[i][j] = v;
     }
     __syncthreads();
+    PP_STAMP(1)
     // valid pair mask -> ioa[j][i] (lower triangle reused as flag storage: 1.0 = valid)
     for (int q = tid; q < npair; q += PP_THREADS) {
       int i, j;
@@ -240,7 +286,11 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
       if (ok) s_any = 1;
     }
     __syncthreads();
+    PP_STAMP(2)
     if (!s_any) break;
+#ifdef GLASS_PP_STAMPS
+    ++iters;
+#endif
     // write-back: box b takes the merge of its LAST valid pair as second element (largest i), else of its
     // last valid pair as first element (largest j); all merges computed from the snapshot
     for (int b = tid; b < n; b += PP_THREADS) {
@@ -250,17 +300,18 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
       if (pi < 0)
         for (int j = n - 1; j > b; --j)
           if (ioa[j][b] == 1.f) { pi = b; pj = j; break; }
-      if (pi >= 0) merge_pair(snap[pi], snap[pj], sc[pi], sc[pj], bx[b]);
+      if (pi >= 0) merge_pair(snap[pi], snap[pj], sc[pi], sc[pj], LdsDPts{reinterpret_cast<DPt*>(work) + b}, bx[b]);
     }
     __syncthreads();
+    PP_STAMP(3)
     // nms_rotated(0.99): IoU matrix, stable descending-score order, greedy suppression, reorder survivors
     for (int q = tid; q < npair; q += PP_THREADS) {
       int i, j;
       pp_pair(q, n, i, j);
       float iou = 0.f;
       if (!pp_far_apart(bx[i], bx[j]))
-        iou = rotated_iou(make_rbox(bx[i][0], bx[i][1], bx[i][2], bx[i][3], bx[i][4]),
-                          make_rbox(bx[j][0], bx[j][1], bx[j][2], bx[j][3], bx[j][4]));
+        iou = rotated_iou_in(make_rbox(bx[i][0], bx[i][1], bx[i][2], bx[i][3], bx[i][4]),
+                             make_rbox(bx[j][0], bx[j][1], bx[j][2], bx[j][3], bx[j][4]), iou_pts);
       ioa[i][j] = iou;
       ioa[j][i] = iou;
     }
@@ -272,6 +323,7 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
       order[rank] = i;
     }
     __syncthreads();
+    PP_STAMP(4)
     // greedy suppression by ONE wavefront (no barriers): lane l owns sorted positions l and l + 64
     if (tid < 64) {
       const int c0 = tid, c1 = tid + 64;
@@ -310,49 +362,26 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
       }
     }
     __syncthreads();
+    PP_STAMP(5)
   }
   __syncthreads();
+  PP_STAMP(5)
 
-  // ---- text decode: argmax per (box, step) by all threads (the IoA matrix storage is free now)
+  // ---- text decode: the survivors' rows of the per-(box, step) argmax / maximum (text_argmax_kernel) into LDS (the
+  // IoA matrix storage is free now)
   int* chr = reinterpret_cast<int*>(&ioa[0][0]);                  // [n][T]
   float* prb = &ioa[0][0] + PP_KMAX * 32;                         // [n][T], T <= 32
   const int n_fin = s_n;
   if (p.do_text) {
-    // 4 lanes per (box, step) row, 64 rows in flight per pass; every lane's loads of a pass are independent
-    // (one memory latency per pass); first maximum wins, as torch.max.  (A whole wavefront per row serialises
-    // 208 row latencies per wavefront: 3x slower than even one thread per row.)
-    constexpr int LPR = 4, CMAX_L = (256 + LPR - 1) / LPR;
-    const int sub = tid & (LPR - 1), grp = tid / LPR;
-    const int nrows = n_fin * p.T;
-    constexpr int G = PP_THREADS / LPR;
-    for (int pass = 0; pass * G < nrows; ++pass) {
-      const int pr = pass * G + grp;
-      const bool live = pr < nrows;                      // every lane stays in the loop for the shuffles
-      const int prc = live ? pr : nrows - 1;
-      const int i = prc / p.T, t = prc - i * p.T;
-      const float* row = p.text + (((long)n_img * p.K + src[i]) * p.T + t) * (long)p.C;
-      float best = -INFINITY;
-      int bi = 0x7fffffff;
-#pragma unroll 8
-      for (int k = 0; k < CMAX_L; ++k) {
-        const int c = sub + LPR * k;
-        if (c >= p.C) break;
-        const float v = row[c];
-        if (bi == 0x7fffffff || v > best) { best = v; bi = c; }
-      }
-#pragma unroll
-      for (int off = 1; off < LPR; off <<= 1) {
-        const float ob = __shfl_xor(best, off);
-        const int oi = __shfl_xor(bi, off);
-        if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
-      }
-      if (live && sub == 0) {
-        chr[i * p.T + t] = bi;
-        prb[i * p.T + t] = best;
-      }
+    for (int e = tid; e < n_fin * p.T; e += PP_THREADS) {
+      const int i = e / p.T, t = e - i * p.T;
+      const long g = ((long)n_img * p.K + src[i]) * p.T + t;
+      chr[e] = p.text_arg[g];
+      prb[e] = p.text_max[g];
     }
   }
   __syncthreads();
+  PP_STAMP(6)
   // per box: word score = product of the probabilities before the first stop symbol and at it (or of all T
   // when there is none), text length = characters before the stop
   for (int i = tid; i < n_fin; i += PP_THREADS) {
@@ -397,26 +426,72 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
       for (int t = 0; t < p.T; ++t) p.out_char[o * p.T + t] = chr[i * p.T + t];
   }
   if (tid == 0) p.out_count[n_img] = m_out;
+#ifdef GLASS_PP_STAMPS
+  PP_STAMP(7)
+  if (tid == 0)
+    printf("[pp] img %d n0 %d iters %d | filter %llu ioa %llu mask %llu merge %llu nms-iou %llu greedy %llu text %llu out %llu | total %llu cycles\n",
+           n_img, cnt, iters, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], tlast - tstart);
+#endif
 }
 
-extern "C" int glass_postprocess_words(const float* boxes, const float* scores, const int* counts, const float* text,
-                                       const float* scale_xy, int N, int K, int T, int C, const float* thresholds8_host,
-                                       int stop_index, float* out_boxes, float* out_scores, float* out_polygons, int* out_src,
-                                       int* out_char, float* out_text_score, int* out_text_len, int* out_count,
-                                       glass_stream_t stream) {
+// Per-(box, step) argmax over the characters (reference text_encoder.py:81-151 `preds_prob.max(dim=2)`): one wavefront
+// per row of `text` [N,K,T,C], the first maximum wins (as torch.max); rows of padding boxes (k >= counts[n]) are skipped
+// and their outputs left untouched.
+__global__ __launch_bounds__(256) void text_argmax_kernel(const float* __restrict__ text, const int* __restrict__ counts, int N, int K,
+                                                          int T, int C, int* __restrict__ out_arg, float* __restrict__ out_max) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)N * K * T) return;
+  const int n = (int)(row / ((long)K * T)), k = (int)((row / T) % K);
+  if (k >= min(counts[n], K)) return;
+  const float* r = text + row * (long)C;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = r[c];
+    if (bi == 0x7fffffff || v > best) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+  }
+  if (lane == 0) { out_arg[row] = bi; out_max[row] = best; }
+}
+
+extern "C" int glass_text_argmax(const float* text, const int* counts, int N, int K, int T, int C, int* out_arg, float* out_max,
+                                 glass_stream_t stream) {
+  if ((long)N * K * T == 0) return GLASS_OK;
+  GLASS_CHECK_ARG(text && counts && out_arg && out_max, "glass_text_argmax: null pointer");
+  GLASS_CHECK_ARG(N > 0 && K > 0 && T > 0 && C > 0, "glass_text_argmax: bad shape N=%d K=%d T=%d C=%d", N, K, T, C);
+  const long rows = (long)N * K * T;
+  GLASS_CHECK_ARG((rows + 3) / 4 <= 0x7fffffffL, "glass_text_argmax: too many rows");
+  hipLaunchKernelGGL(text_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, text, counts, N, K, T,
+                     C, out_arg, out_max);
+  GLASS_CHECK_LAUNCH("glass_text_argmax");
+  return GLASS_OK;
+}
+
+extern "C" int glass_postprocess_words(const float* boxes, const float* scores, const int* counts, const int* text_arg,
+                                       const float* text_max, const float* scale_xy, int N, int K, int T,
+                                       const float* thresholds8_host, int stop_index, float* out_boxes, float* out_scores,
+                                       float* out_polygons, int* out_src, int* out_char, float* out_text_score, int* out_text_len,
+                                       int* out_count, glass_stream_t stream) {
   if (N == 0) return GLASS_OK;
   GLASS_CHECK_ARG(K >= 0 && K <= PP_KMAX, "glass_postprocess_words: K=%d (max %d)", K, PP_KMAX);
   GLASS_CHECK_ARG(counts && thresholds8_host && out_count, "glass_postprocess_words: null pointer");
   GLASS_CHECK_ARG(K == 0 || (boxes && scores && out_boxes && out_scores && out_polygons && out_src && out_char &&
                              out_text_score && out_text_len), "glass_postprocess_words: null pointer");
-  GLASS_CHECK_ARG(!text || (T > 0 && T <= 32 && C > 0), "glass_postprocess_words: text needs 0 < T <= 32, C > 0");
+  GLASS_CHECK_ARG((text_arg == nullptr) == (text_max == nullptr), "glass_postprocess_words: text_arg and text_max go together");
+  GLASS_CHECK_ARG(!text_arg || (T > 0 && T <= 32), "glass_postprocess_words: text needs 0 < T <= 32");
   PPParams p;
-  p.boxes = boxes; p.scores = scores; p.counts = counts; p.text = text; p.scale_xy = scale_xy;
-  p.N = N; p.K = K; p.T = text ? T : 1; p.C = C;
+  p.boxes = boxes; p.scores = scores; p.counts = counts; p.text_arg = text_arg; p.text_max = text_max; p.scale_xy = scale_xy;
+  p.N = N; p.K = K; p.T = text_arg ? T : 1;
   p.min_box_dim = thresholds8_host[0]; p.valid_score = thresholds8_host[1]; p.detect_thr = thresholds8_host[2];
   p.merge_ioa = thresholds8_host[3]; p.height_ratio = thresholds8_host[4]; p.max_angle_diff = thresholds8_host[5];
   p.minimal_ioa = thresholds8_host[6]; p.text_thr = thresholds8_host[7];
-  p.stop_index = stop_index; p.do_text = text ? 1 : 0;
+  p.stop_index = stop_index; p.do_text = text_arg ? 1 : 0;
   p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_poly = out_polygons; p.out_src = out_src; p.out_char = out_char;
   p.out_text_score = out_text_score; p.out_text_len = out_text_len; p.out_count = out_count;
   hipLaunchKernelGGL(postprocess_words_kernel, dim3(N), dim3(PP_THREADS), 0, (hipStream_t)stream, p);

@@ -39,7 +39,16 @@ __device__ __forceinline__ bool hull_less(Pt A, Pt B) {
   return t > 0;
 }
 
-__device__ inline float rotated_iou(const RBox& r1, const RBox& r2) {
+// The algorithm's point list (up to 24 entries, indexed dynamically).  PrivPts keeps it in private memory (scratch: every
+// access is a memory round trip); a kernel with LDS to spare passes its own type with the same operator[] (postprocess.hip:
+// one column per thread) - the arithmetic, and so the result, is the same bit for bit.
+struct PrivPts {
+  Pt a[24];
+  __device__ __forceinline__ Pt& operator[](int i) { return a[i]; }
+};
+
+template <class PtArr>
+__device__ inline float rotated_iou_in(const RBox& r1, const RBox& r2, PtArr& ip) {
 #pragma clang fp contract(off)
   const float area1 = r1.w * r1.h, area2 = r2.w * r2.h;
   if (area1 < 1e-14f || area2 < 1e-14f) return 0.f;
@@ -61,7 +70,6 @@ __device__ inline float rotated_iou(const RBox& r1, const RBox& r2) {
     v1[i] = psub(p1[(i + 1) & 3], p1[i]);
     v2[i] = psub(p2[(i + 1) & 3], p2[i]);
   }
-  Pt ip[24];
   int num = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -104,7 +112,7 @@ __device__ inline float rotated_iou(const RBox& r1, const RBox& r2) {
   for (int i = 1; i < num; ++i)
     if (ip[i].y < ip[t].y || (ip[i].y == ip[t].y && ip[i].x < ip[t].x)) t = i;
   const Pt start = ip[t];
-  Pt q[24];
+  PtArr& q = ip;                                   // (shifted in place)
   for (int i = 0; i < num; ++i) q[i] = psub(ip[i], start);
   { const Pt tmp = q[0]; q[0] = q[t]; q[t] = tmp; }
   for (int i = 2; i < num; ++i) {
@@ -126,11 +134,17 @@ __device__ inline float rotated_iou(const RBox& r1, const RBox& r2) {
     }
     if (m > 2) {
       float area = 0.f;
-      for (int i = 1; i < m - 1; ++i) area += fabsf(cross2(psub(q[i], q[0]), psub(q[i + 1], q[0])));
+      const Pt q0 = q[0];
+      for (int i = 1; i < m - 1; ++i) area += fabsf(cross2(psub(q[i], q0), psub(q[i + 1], q0)));
       inter = area / 2.0f;
     }
   }
   return inter / (area1 + area2 - inter);
+}
+
+__device__ inline float rotated_iou(const RBox& r1, const RBox& r2) {
+  PrivPts pts;
+  return rotated_iou_in(r1, r2, pts);
 }
 
 __device__ __forceinline__ RBox make_rbox(float cx, float cy, float w, float h, float a) {

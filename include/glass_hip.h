@@ -290,20 +290,27 @@ int glass_detections_finalize(const float* boxes, const float* scores, const flo
  * post_processor_rotated_boxes.py:66-87: small-box filter, score >= VALID_CONFIDENCE, iterative pair merge
  * with min-area-rect + NMS 0.99, score >= DETECT_THRESHOLD, polygons) followed by the text decode and
  * text-score filter (post_processor_academic.py:26-35, text_evaluator.py:323-348, text_encoder.py:81-151).
- * boxes [N,K,5], scores [N,K], counts [N] (device), text [N,K,T,C] softmax rows or NULL (then no text
- * filter), scale_xy [N,2] device floats or NULL (GlassRunner's un-scaling, glass_runner.py:100-101; a
- * (1,1) entry is skipped exactly like the reference's `if scale_ratio != 1`).
+ * boxes [N,K,5], scores [N,K], counts [N] (device); text_arg / text_max [N,K,T] = argmax character and its probability
+ * per decoding step (glass_text_argmax below) or both NULL (then no text filter); scale_xy [N,2] device floats or NULL
+ * (GlassRunner's un-scaling, glass_runner.py:100-101; a (1,1) entry is skipped exactly like the reference's
+ * `if scale_ratio != 1`).
  * thresholds8_host = {MIN_BOX_DIMENSION, VALID_CONFIDENCE, DETECT_THRESHOLD, MERGE_IOA_THRESH,
  * PAIRS_HEIGHT_RATIO_THRESH, MAX_ANGLE_DIFF, minimal_ioa (0.01), TEXT_THRESHOLD}; stop_index = index of '[s]'.
  * Outputs (padded to K, out_count[n] valid rows, in the reference's output order): boxes, scores,
  * polygons [N,K,4,2], out_src [N,K] source slot of each survivor (to gather other fields), out_char
  * [N,K,T] argmax character index per step, out_text_score [N,K], out_text_len [N,K] (characters before the
- * stop symbol).  K <= 128.                                                                         */
-int glass_postprocess_words(const float* boxes, const float* scores, const int* counts, const float* text,
-                            const float* scale_xy, int N, int K, int T, int C, const float* thresholds8_host,
-                            int stop_index, float* out_boxes, float* out_scores, float* out_polygons, int* out_src,
-                            int* out_char, float* out_text_score, int* out_text_len, int* out_count,
-                            glass_stream_t stream);
+ * stop symbol).  K <= 128, T <= 32.                                                               */
+int glass_postprocess_words(const float* boxes, const float* scores, const int* counts, const int* text_arg,
+                            const float* text_max, const float* scale_xy, int N, int K, int T,
+                            const float* thresholds8_host, int stop_index, float* out_boxes, float* out_scores,
+                            float* out_polygons, int* out_src, int* out_char, float* out_text_score, int* out_text_len,
+                            int* out_count, glass_stream_t stream);
+
+/* The decode's argmax (reference glass/modeling/recognition/text_encoder.py:81-151 `preds_prob.max(dim=2)`, consumed by
+ * text_evaluator.py:323-348): text [N,K,T,C] probability rows -> out_arg [N,K,T] first index of the row maximum,
+ * out_max [N,K,T] the maximum; rows of boxes k >= counts[n] are skipped (outputs untouched).  One wavefront per row.  */
+int glass_text_argmax(const float* text, const int* counts, int N, int K, int T, int C, int* out_arg, float* out_max,
+                      glass_stream_t stream);
 
 /* pairwise rotated IoU matrix out[n1][n2] (d2 pairwise_iou_rotated; glass/structures/boxes.py:33,
  * used by the post-processor's pairwise_ioa_rotated).                                     */
