@@ -54,8 +54,9 @@ struct LdsDPts {
   __device__ __forceinline__ DPt& operator[](int i) const { return base[i * PP_KMAX]; }
 };
 
-// `A`: 32 points of storage (sorted points 0..7, hull 8..23, upper chain 24..31)
-__device__ void min_area_rect8(const float* pts /*[8][2]*/, LdsDPts A, double& cx, double& cy, double& w, double& h, double& ang) {
+// Hull of the 8 corner points of two boxes.  `A`: 32 points of storage (sorted points 0..7, hull 8..23, upper chain 24..31);
+// returns the number of hull points (<= 8).
+__device__ int merge_hull(const float* pts /*[8][2]*/, LdsDPts A) {
   const LdsDPts p{A.base}, hull{A.base + 8 * PP_KMAX}, upper{A.base + 24 * PP_KMAX};
   int n = 8;
   for (int i = 0; i < 8; ++i) { p[i].x = (double)pts[2 * i]; p[i].y = (double)pts[2 * i + 1]; }
@@ -88,35 +89,29 @@ __device__ void min_area_rect8(const float* pts /*[8][2]*/, LdsDPts A, double& c
     hn = nl - 1;
     for (int i = 0; i < nu - 1; ++i) hull[hn++] = upper[i];
   }
-  if (hn == 1) { const DPt h0 = hull[0]; cx = h0.x; cy = h0.y; w = 0; h = 0; ang = 0; return; }
-  if (hn == 2) {
-    const DPt h0 = hull[0], h1 = hull[1];
-    const double dx = h1.x - h0.x, dy = h1.y - h0.y;
-    cx = (h0.x + h1.x) / 2; cy = (h0.y + h1.y) / 2;
-    w = hypot(dx, dy); h = 0; ang = atan2(dy, dx) * 57.29577951308232;
-    return;
+  return hn;
+}
+
+// bounding rectangle of the hull with one side along hull edge i (false: zero-length edge)
+struct EdgeRect { double area, cx, cy, w, h, ang; };
+__device__ bool hull_edge_rect(LdsDPts hull, int hn, int i, EdgeRect& r) {
+  const DPt a = hull[i], b = hull[(i + 1) % hn];
+  const double ex = b.x - a.x, ey = b.y - a.y;
+  const double nrm = hypot(ex, ey);
+  if (nrm == 0) return false;
+  const double ux = ex / nrm, uy = ey / nrm, vx = -uy, vy = ux;
+  double pumin = 1e300, pumax = -1e300, pvmin = 1e300, pvmax = -1e300;
+  for (int k = 0; k < hn; ++k) {
+    const DPt hk = hull[k];
+    const double pu = hk.x * ux + hk.y * uy, pv = hk.x * vx + hk.y * vy;
+    pumin = fmin(pumin, pu); pumax = fmax(pumax, pu); pvmin = fmin(pvmin, pv); pvmax = fmax(pvmax, pv);
   }
-  double best = -1.0;
-  for (int i = 0; i < hn; ++i) {
-    const DPt a = hull[i], b = hull[(i + 1) % hn];
-    const double ex = b.x - a.x, ey = b.y - a.y;
-    const double nrm = hypot(ex, ey);
-    if (nrm == 0) continue;
-    const double ux = ex / nrm, uy = ey / nrm, vx = -uy, vy = ux;
-    double pumin = 1e300, pumax = -1e300, pvmin = 1e300, pvmax = -1e300;
-    for (int k = 0; k < hn; ++k) {
-      const DPt hk = hull[k];
-      const double pu = hk.x * ux + hk.y * uy, pv = hk.x * vx + hk.y * vy;
-      pumin = fmin(pumin, pu); pumax = fmax(pumax, pu); pvmin = fmin(pvmin, pv); pvmax = fmax(pvmax, pv);
-    }
-    const double ww = pumax - pumin, hh = pvmax - pvmin;
-    if (best < 0 || ww * hh < best) {
-      best = ww * hh;
-      const double cu = (pumax + pumin) / 2, cv = (pvmax + pvmin) / 2;
-      cx = ux * cu + vx * cv; cy = uy * cu + vy * cv; w = ww; h = hh;
-      ang = atan2(uy, ux) * 57.29577951308232;
-    }
-  }
+  const double ww = pumax - pumin, hh = pvmax - pvmin;
+  r.area = ww * hh;
+  const double cu = (pumax + pumin) / 2, cv = (pvmax + pvmin) / 2;
+  r.cx = ux * cu + vx * cv; r.cy = uy * cu + vy * cv; r.w = ww; r.h = hh;
+  r.ang = atan2(uy, ux) * 57.29577951308232;
+  return true;
 }
 
 __device__ inline float floor_mod_pp(float a, float b) {   // torch.remainder semantics
@@ -143,15 +138,16 @@ __device__ inline void box_polygon(const float* b, float* poly /*[4][2]*/) {
   poly[6] = cx - (h * s + w * c) / 2;  poly[7] = cy + (h * c - w * s) / 2;
 }
 
-// _merge_rotated_boxes (:187-216) + polygons_to_rotated_boxes (:253-286) for one pair
-__device__ void merge_pair(const float* b1, const float* b2, float s1, float s2, LdsDPts A, float* out) {
-  float pts[16];
+// _merge_rotated_boxes (:187-216) + polygons_to_rotated_boxes (:253-286) for one pair, in two parts around the minimum-area
+// rectangle (cx, cy, w, h, ang) of the pair's 8 corners: merge_corners before, merge_finish after
+__device__ inline void merge_corners(const float* b1, const float* b2, float* pts /*[8][2]*/) {
   box_polygon(b1, pts);
   box_polygon(b2, pts + 8);
+}
+__device__ void merge_finish(const float* b1, const float* b2, float s1, float s2, double cx, double cy, double w, double h, double ang,
+                             float* out) {
   const float a1 = b1[4] * 3.14159265358979323846f / 180.f, a2 = b2[4] * 3.14159265358979323846f / 180.f;
   const double orient = (double)(s1 >= s2 ? a1 : a2);          // radians (reference quirk)
-  double cx, cy, w, h, ang;
-  min_area_rect8(pts, A, cx, cy, w, h, ang);
   double angle = 90.0 - ang;
   double diff = pymod((orient - angle) + 180.0, 360.0) - 180.0;
   double width, height;
@@ -182,13 +178,49 @@ __device__ __forceinline__ void pp_pair(int q, int n, int& i, int& j) {
   j = q - r * (2 * n - r - 1) / 2 + r + 1;
 }
 
+// All pairs (i < j) of n boxes: on_far(i, j) for the far-apart ones right away; the others - the ones that run the long
+// polygon-clipping code - are first collected per wavefront (ballot compaction into `queue`, 128 entries per wavefront)
+// and handed to on_near(i, j) 64 at a time, so that a wavefront runs the long path with all lanes busy and about
+// (near pairs / 256) times instead of once per loop trip with whatever lanes happen to need it.
+template <class Far, class Near>
+__device__ __forceinline__ void pp_for_pairs(int n, const float (*B)[5], unsigned short* queue, int tid, Far on_far, Near on_near) {
+  const int npair = n * (n - 1) / 2, lane = tid & 63;
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int qn = 0;                                                       // (wavefront-uniform)
+  for (int base = tid & ~63; base < npair; base += PP_THREADS) {
+    const int q = base + lane;
+    int i = 0, j = 0;
+    bool near = false;
+    if (q < npair) {
+      pp_pair(q, n, i, j);
+      near = !pp_far_apart(B[i], B[j]);
+      if (!near) on_far(i, j);
+    }
+    const unsigned long long m = __ballot(near);
+    if (near) queue[qn + __popcll(m & below)] = (unsigned short)(i * PP_KMAX + j);
+    qn += __popcll(m);
+    if (qn >= 64) {
+      qn -= 64;
+      const int e = queue[qn + lane];
+      on_near(e / PP_KMAX, e % PP_KMAX);
+    }
+  }
+  if (lane < qn) {
+    const int e = queue[lane];
+    on_near(e / PP_KMAX, e % PP_KMAX);
+  }
+}
+
 __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams p) {
   __shared__ float bx[PP_KMAX][5], snap[PP_KMAX][5], tmpb[PP_KMAX][5];
   __shared__ float sc[PP_KMAX], tmps[PP_KMAX];
   __shared__ int src[PP_KMAX], tmpi[PP_KMAX], order[PP_KMAX];
   __shared__ float ioa[PP_KMAX][PP_KMAX + 1];      // IoA (merge) / IoU (NMS) matrix
   __shared__ unsigned char flag[PP_KMAX];
-  __shared__ int s_n, s_any, s_wave_cnt[2];
+  __shared__ int s_n, s_any, s_wave_cnt[2], s_reuse;
+  __shared__ float rc2[PP_KMAX], rs2[PP_KMAX], tmpc2[PP_KMAX], tmps2[PP_KMAX];   // make_rbox's half cos / sin of bx (= of snap until the write-back)
+  __shared__ int old_of[PP_KMAX], tmpo[PP_KMAX], s_hn[PP_KMAX];
+  __shared__ unsigned short queue[PP_THREADS / 64][128];
   // the threads' point lists (rotated IoU: 24 points per thread; merge: 32 double points per box); the phases that use the
   // two views are separated by barriers
   __shared__ __attribute__((aligned(16))) unsigned char work[PP_WORK_BYTES];
@@ -238,9 +270,14 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
       sc[d] = sj;
       src[d] = j;
     }
-    if (tid == 0) s_n = s_wave_cnt[0] + s_wave_cnt[1];
+    if (tid == 0) { s_n = s_wave_cnt[0] + s_wave_cnt[1]; s_reuse = 0; }
   }
   __syncthreads();
+  for (int i = tid; i < s_n; i += PP_THREADS) {
+    const RBox r = make_rbox(bx[i][0], bx[i][1], bx[i][2], bx[i][3], bx[i][4]);
+    rc2[i] = r.c2; rs2[i] = r.s2;
+  }
+  auto rbox_of = [&](const float (*B)[5], int i) { return RBox{B[i][0], B[i][1], B[i][2], B[i][3], rc2[i], rs2[i]}; };
   PP_STAMP(0)
 
   // ---- merge_intersecting_boxes
@@ -250,29 +287,36 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
     for (int i = tid; i < n * 5; i += PP_THREADS) snap[i / 5][i % 5] = bx[i / 5][i % 5];
     if (tid == 0) s_any = 0;
     __syncthreads();
-    // IoA matrix (upper triangle), same algebra as pairwise_ioa_rotated (glass/structures/boxes.py:33-48)
+    // IoA matrix (upper triangle), same algebra as pairwise_ioa_rotated (glass/structures/boxes.py:33-48): from the pairs'
+    // IoU.  From the second iteration on that IoU is the one the previous iteration's NMS computed on these very boxes
+    // (same arguments in the same order as long as the score sort did not swap anybody: `s_reuse`), only re-indexed.
     const int npair = n * (n - 1) / 2;
-    for (int q = tid; q < npair; q += PP_THREADS) {
-      int i, j;
-      pp_pair(q, n, i, j);
-      float v = 0.f;
-      if (!pp_far_apart(snap[i], snap[j])) {
-        const float iou = rotated_iou_in(make_rbox(snap[i][0], snap[i][1], snap[i][2], snap[i][3], snap[i][4]),
-                                         make_rbox(snap[j][0], snap[j][1], snap[j][2], snap[j][3], snap[j][4]), iou_pts);
-        const float a1 = snap[i][2] * snap[i][3], a2 = snap[j][2] * snap[j][3];
-        const float inter = (a1 + a2) * iou / (1.f + iou);
-        v = inter / fminf(a1, a2);
+    auto ioa_of = [&](int i, int j, float iou) {
+      const float a1 = snap[i][2] * snap[i][3], a2 = snap[j][2] * snap[j][3];
+      const float inter = (a1 + a2) * iou / (1.f + iou);
+      return inter / fminf(a1, a2);
+    };
+    // Storage: the NMS writes its IoU into the UPPER triangle (row < column, in its own box order); the IoA of this
+    // iteration goes into the LOWER triangle ([j][i]), so the re-indexing reads and writes never touch the same entry
+    // and needs no staging; the pair flags below then overwrite the upper triangle, which nobody reads any more.
+    if (s_reuse) {
+      for (int q = tid; q < npair; q += PP_THREADS) {
+        int i, j;
+        pp_pair(q, n, i, j);
+        ioa[j][i] = pp_far_apart(snap[i], snap[j]) ? 0.f : ioa_of(i, j, ioa[old_of[i]][old_of[j]]);
       }
-      ioa[i][j] = v;
+    } else {
+      pp_for_pairs(n, snap, queue[tid >> 6], tid, [&](int i, int j) { ioa[j][i] = 0.f; },
+                   [&](int i, int j) { ioa[j][i] = ioa_of(i, j, rotated_iou_in(rbox_of(snap, i), rbox_of(snap, j), iou_pts)); });
     }
     __syncthreads();
     PP_STAMP(1)
-    // valid pair mask -> ioa[j][i] (lower triangle reused as flag storage: 1.0 = valid)
+    // valid pair mask -> ioa[i][j] (upper triangle as flag storage: 1.0 = valid)
     for (int q = tid; q < npair; q += PP_THREADS) {
       int i, j;
       pp_pair(q, n, i, j);
       bool ok = false;
-      const float v = ioa[i][j];
+      const float v = ioa[j][i];
       if (v >= p.minimal_ioa) {
         float ad = snap[j][4] - snap[i][4];
         ad = fabsf(floor_mod_pp(ad + 180.f, 360.f) - 180.f);
@@ -282,7 +326,7 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
         const bool vs = fminf(sc[i], sc[j]) >= p.valid_score;
         ok = sim_angle && sim_h && vs && (v >= p.merge_ioa);
       }
-      ioa[j][i] = ok ? 1.f : 0.f;
+      ioa[i][j] = ok ? 1.f : 0.f;
       if (ok) s_any = 1;
     }
     __syncthreads();
@@ -293,28 +337,60 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
 #endif
     // write-back: box b takes the merge of its LAST valid pair as second element (largest i), else of its
     // last valid pair as first element (largest j); all merges computed from the snapshot
-    for (int b = tid; b < n; b += PP_THREADS) {
+    // Eight lanes per box: lane 0 builds the hull of the pair's corners (LDS column b), every lane evaluates the bounding
+    // rectangle along one hull edge (<= 8), and the reference loop's choice - the first edge of strictly smaller area -
+    // is folded over the lanes' areas in edge order.
+    for (int b0 = 0; b0 < n; b0 += PP_THREADS / 8) {
+      const int b = b0 + (tid >> 3), gl = tid & 7;
       int pi = -1, pj = -1;
-      for (int i = b - 1; i >= 0; --i)
-        if (ioa[b][i] == 1.f) { pi = i; pj = b; break; }
-      if (pi < 0)
-        for (int j = n - 1; j > b; --j)
-          if (ioa[j][b] == 1.f) { pi = b; pj = j; break; }
-      if (pi >= 0) merge_pair(snap[pi], snap[pj], sc[pi], sc[pj], LdsDPts{reinterpret_cast<DPt*>(work) + b}, bx[b]);
+      if (b < n) {
+        for (int i = b - 1; i >= 0; --i)
+          if (ioa[i][b] == 1.f) { pi = i; pj = b; break; }
+        if (pi < 0)
+          for (int j = n - 1; j > b; --j)
+            if (ioa[b][j] == 1.f) { pi = b; pj = j; break; }
+      }
+      const bool act = pi >= 0;
+      const LdsDPts A{reinterpret_cast<DPt*>(work) + (act ? b : 0)}, hull{A.base + 8 * PP_KMAX};
+      if (act && gl == 0) {
+        float pts[16];
+        merge_corners(snap[pi], snap[pj], pts);
+        s_hn[b] = merge_hull(pts, A);
+      }
+      __syncthreads();
+      const int hn = act ? s_hn[b] : 0;
+      EdgeRect r{0., 0., 0., 0., 0., 0.};
+      const bool ok = act && hn >= 3 && gl < hn && hull_edge_rect(hull, hn, gl, r);
+      int win = 0;
+      double best = -1.0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const double ae = __shfl(r.area, e, 8);
+        const int oke = __shfl((int)ok, e, 8);
+        if (oke && (best < 0 || ae < best)) { best = ae; win = e; }
+      }
+      double cx = __shfl(r.cx, win, 8), cy = __shfl(r.cy, win, 8), w = __shfl(r.w, win, 8), h = __shfl(r.h, win, 8),
+             ang = __shfl(r.ang, win, 8);
+      if (act && gl == 0) {
+        if (hn == 1) {
+          const DPt h0 = hull[0];
+          cx = h0.x; cy = h0.y; w = 0; h = 0; ang = 0;
+        } else if (hn == 2) {
+          const DPt h0 = hull[0], h1 = hull[1];
+          const double dx = h1.x - h0.x, dy = h1.y - h0.y;
+          cx = (h0.x + h1.x) / 2; cy = (h0.y + h1.y) / 2;
+          w = hypot(dx, dy); h = 0; ang = atan2(dy, dx) * 57.29577951308232;
+        }
+        merge_finish(snap[pi], snap[pj], sc[pi], sc[pj], cx, cy, w, h, ang, bx[b]);
+        const RBox rb = make_rbox(bx[b][0], bx[b][1], bx[b][2], bx[b][3], bx[b][4]);
+        rc2[b] = rb.c2; rs2[b] = rb.s2;
+      }
     }
     __syncthreads();
     PP_STAMP(3)
     // nms_rotated(0.99): IoU matrix, stable descending-score order, greedy suppression, reorder survivors
-    for (int q = tid; q < npair; q += PP_THREADS) {
-      int i, j;
-      pp_pair(q, n, i, j);
-      float iou = 0.f;
-      if (!pp_far_apart(bx[i], bx[j]))
-        iou = rotated_iou_in(make_rbox(bx[i][0], bx[i][1], bx[i][2], bx[i][3], bx[i][4]),
-                             make_rbox(bx[j][0], bx[j][1], bx[j][2], bx[j][3], bx[j][4]), iou_pts);
-      ioa[i][j] = iou;
-      ioa[j][i] = iou;
-    }
+    pp_for_pairs(n, bx, queue[tid >> 6], tid, [&](int i, int j) { ioa[i][j] = 0.f; },
+                 [&](int i, int j) { ioa[i][j] = rotated_iou_in(rbox_of(bx, i), rbox_of(bx, j), iou_pts); });
     // stable descending order by rank counting (ties keep the lower index first, as the host's stable sort)
     for (int i = tid; i < n; i += PP_THREADS) {
       const float si = sc[i];
@@ -328,14 +404,39 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
     if (tid < 64) {
       const int c0 = tid, c1 = tid + 64;
       const int o0 = c0 < n ? order[c0] : 0, o1 = c1 < n ? order[c1] : 0;
-      int rem0 = c0 < n ? 0 : 1, rem1 = c1 < n ? 0 : 1;
-      for (int a = 0; a < n; ++a) {
-        const int ra = a < 64 ? __shfl(rem0, a) : __shfl(rem1, a - 64);
-        if (ra) continue;                                    // wave-uniform
-        const int i = order[a];
-        if (c0 > a && !rem0 && ioa[i][o0] >= 0.99f) rem0 = 1;
-        if (c1 > a && c1 < n && !rem1 && ioa[i][o1] >= 0.99f) rem1 = 1;
+      // who could suppress my two positions: bit a of (s0l, s0h) / (s1l, s1h) = the box at sorted position a < c has
+      // IoU >= 0.99 with mine (independent LDS reads); then the sequential part runs on wavefront-uniform 128-bit masks:
+      // position a, if still alive, removes every later position that has bit a set (one ballot each)
+      unsigned long long s0l = 0, s0h = 0, s1l = 0, s1h = 0;
+      for (int a0 = 0; a0 < n; a0 += 8) {                     // (8 positions per trip: 8 + 16 independent LDS reads in flight)
+        int ia[8];
+        float v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ia[u] = order[min(a0 + u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v0[u] = ioa[min(ia[u], o0)][max(ia[u], o0)];
+          v1[u] = ioa[min(ia[u], o1)][max(ia[u], o1)];
+        }
+        unsigned int m0 = 0, m1 = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int a = a0 + u;
+          m0 |= (a < n && a < c0 && c0 < n && v0[u] >= 0.99f) ? (1u << u) : 0u;
+          m1 |= (a < n && a < c1 && c1 < n && v1[u] >= 0.99f) ? (1u << u) : 0u;
+        }
+        if (a0 < 64) { s0l |= (unsigned long long)m0 << a0; s1l |= (unsigned long long)m1 << a0; }
+        else { s0h |= (unsigned long long)m0 << (a0 - 64); s1h |= (unsigned long long)m1 << (a0 - 64); }
       }
+      unsigned long long reml = n >= 64 ? 0ull : (~0ull << n), remh = n >= 128 ? 0ull : (n <= 64 ? ~0ull : (~0ull << (n - 64)));
+      for (int a = 0; a < n; ++a) {
+        const bool gone = a < 64 ? (reml >> a) & 1 : (remh >> (a - 64)) & 1;
+        if (gone) continue;                                  // wave-uniform
+        const bool h0 = a < 64 ? (s0l >> a) & 1 : (s0h >> (a - 64)) & 1, h1 = a < 64 ? (s1l >> a) & 1 : (s1h >> (a - 64)) & 1;
+        reml |= __ballot(h0);
+        remh |= __ballot(h1);
+      }
+      const int rem0 = (int)((reml >> tid) & 1), rem1 = (int)((remh >> tid) & 1);
       // ordered compaction of the survivors (sorted order)
       const unsigned long long k0 = __ballot(c0 < n && !rem0), k1 = __ballot(c1 < n && !rem1);
       const unsigned long long below = tid == 0 ? 0ull : (~0ull >> (64 - tid));
@@ -344,13 +445,15 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
         for (int e = 0; e < 5; ++e) tmpb[d0][e] = bx[o0][e];
         tmps[d0] = sc[o0];
         tmpi[d0] = src[o0];
+        tmpo[d0] = o0; tmpc2[d0] = rc2[o0]; tmps2[d0] = rs2[o0];
       }
       if (c1 < n && !rem1) {
         for (int e = 0; e < 5; ++e) tmpb[d1][e] = bx[o1][e];
         tmps[d1] = sc[o1];
         tmpi[d1] = src[o1];
+        tmpo[d1] = o1; tmpc2[d1] = rc2[o1]; tmps2[d1] = rs2[o1];
       }
-      if (tid == 0) s_n = __popcll(k0) + __popcll(k1);
+      if (tid == 0) { s_n = __popcll(k0) + __popcll(k1); s_reuse = 1; }
     }
     __syncthreads();
     {
@@ -359,6 +462,8 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
         for (int e = 0; e < 5; ++e) bx[i][e] = tmpb[i][e];
         sc[i] = tmps[i];
         src[i] = tmpi[i];
+        old_of[i] = tmpo[i]; rc2[i] = tmpc2[i]; rs2[i] = tmps2[i];
+        if (i > 0 && tmpo[i - 1] > tmpo[i]) s_reuse = 0;      // the sort moved a lower-scored box behind: argument orders flip
       }
     }
     __syncthreads();
