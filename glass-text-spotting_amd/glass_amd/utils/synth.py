@@ -302,3 +302,15 @@ def widen_dynamic_range(sd, seed: int = 77, conv_gain=(1.5, 2.5), gamma=(1.0, 3.
             gain *= boost_conv(q + "conv2")
             out[q + "bn2.weight"] /= gain
     return out
+
+
+def pattern_text(N: int, K: int, T: int = 26, C: int = 97, stop_index: int = 94) -> torch.Tensor:
+    """Peaked character distributions [N,K,T,C] from integer arithmetic (exactly reproducible on any host): probability 0.9 at
+    class (7 n + 3 k + 5 t) % C, the stop symbol at step (k % 7) + 2, 0.1 / (C - 1) elsewhere.  Input of the word post-processor's
+    regression fixture (scripts/make_pp_regression.py, tests/golden/postprocess_words_regression.npz)."""
+    n, k, t = torch.meshgrid(torch.arange(N), torch.arange(K), torch.arange(T), indexing="ij")
+    peak = (7 * n + 3 * k + 5 * t) % C
+    peak = torch.where(t == (k % 7) + 2, torch.full_like(peak, stop_index), peak)
+    text = torch.full((N, K, T, C), 0.1 / (C - 1), dtype=torch.float32)
+    text.scatter_(3, peak.unsqueeze(-1), 0.9)
+    return text

@@ -200,6 +200,62 @@ def test_device_postprocessor_equals_host_restatement_with_text():
         np.testing.assert_allclose(devr.pred_text_scores.cpu().numpy(), np.array(tscores, dtype=np.float32), rtol=1e-5, atol=1e-7)
 
 
+def test_postprocess_words_regression_fixture(golden_dir):
+    """The word post-processor's outputs on committed detections (the bench's 8 images, dense scenes of 100 / 128 boxes with random
+    scores, un-scaling, ragged counts) are EXACTLY those of the fixture (scripts/make_pp_regression.py: written by the round-4 kernel;
+    the round-3 kernel, pinned on the host restatement above, reproduces it bit for bit).  Guards the restructured merge loop:
+    queued near pairs, 8 lanes per merge, the NMS IoU re-indexed into the next iteration's IoA, bit-mask suppression."""
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import pattern_text
+    g = np.load(os.path.join(golden_dir, "postprocess_words_regression.npz"))
+    dev = torch.device("cuda:0")
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert names == ["bench", "dense100", "dense100_strict", "dense128_scaled", "few7_scaled"]
+    for name in names:
+        b, sc, cnt = (torch.from_numpy(g[f"{name}/in_{k}"]).to(dev) for k in ("boxes", "scores", "counts"))
+        s = torch.from_numpy(g[f"{name}/in_scale_xy"]).to(dev) if f"{name}/in_scale_xy" in g.files else None
+        o = K.postprocess_words(b, sc, cnt, pattern_text(*sc.shape).to(dev), s, [float(v) for v in g[f"{name}/thresholds"]], 94)
+        for k, v in o.items():
+            assert np.array_equal(v.cpu().numpy(), g[f"{name}/out_{k}"]), (name, k)
+        assert int(o["count"].sum()) > 0
+        print(f"[post-processor regression] {name}: kept {o['count'].tolist()} (exact)")
+
+
+def test_text_argmax_matches_torch_max():
+    """glass_text_argmax (a wavefront per row; reference text_encoder.py:81-151 `preds_prob.max(dim=2)`): first index of the row
+    maximum, ties included; rows of padding boxes are not touched."""
+    from glass_amd.ops import native as K
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for N, KK, T, C in ((3, 5, 26, 97), (1, 1, 1, 1), (2, 7, 4, 64), (2, 3, 5, 200), (1, 2, 32, 65)):
+        text = torch.softmax(torch.randn((N, KK, T, C), generator=g) * 3, -1)
+        if C > 3:
+            text[0, 0, 0, :] = 0.0
+            text[0, 0, 0, [C - 1, 2, C // 2]] = 0.5          # a three-way tie: index 2 wins
+        cnt = torch.randint(0, KK + 1, (N,), generator=g, dtype=torch.int32)
+        cnt[0] = KK
+        arg, mx = K.text_argmax(text.to(dev), cnt.to(dev))
+        ref_mx, ref_arg = text.max(dim=3)
+        for n in range(N):
+            c = int(cnt[n])
+            assert torch.equal(arg[n, :c].cpu(), ref_arg[n, :c].to(torch.int32)), (N, KK, T, C, n)
+            assert torch.equal(mx[n, :c].cpu(), ref_mx[n, :c])
+        if C > 3:
+            assert int(arg[0, 0, 0]) == 2
+    # padding rows stay untouched
+    text = torch.rand((1, 4, 3, 10))
+    sentinel_arg = torch.full((1, 4, 3), -7, dtype=torch.int32, device=dev)
+    from glass_amd._lib import check, lib
+    from ctypes import c_void_p
+    mx = torch.full((1, 4, 3), -1.0, device=dev)
+    t = text.to(dev)
+    cnt = torch.tensor([2], dtype=torch.int32, device=dev)
+    check(lib().glass_text_argmax(c_void_p(t.data_ptr()), c_void_p(cnt.data_ptr()), 1, 4, 3, 10, c_void_p(sentinel_arg.data_ptr()),
+                                  c_void_p(mx.data_ptr()), c_void_p(K.stream_handle())), "glass_text_argmax")
+    torch.cuda.synchronize()
+    assert (sentinel_arg[0, 2:] == -7).all() and (mx[0, 2:] == -1.0).all() and (sentinel_arg[0, :2] >= 0).all()
+
+
 def test_runner_batch_with_device_postprocess_equals_single_calls():
     from glass_amd.inference.glass_runner import GlassRunner
     from glass_amd.utils.synth import make_image, make_state_dict
