@@ -25,8 +25,16 @@
 // degree-valued orientation correction (reference quirk, :203-206 vs :267).
 #include "rotated_iou.h"
 
+// No fused multiply-add anywhere in this file: the reference computes these boxes with separate torch float32 ops and the
+// pinned restatement of cv2.minAreaRect (glass_amd/postprocess/post_processor_rotated_boxes.py:min_area_rect) in numpy
+// float64, neither of which fuses.  With hipcc's default (fuse wherever it can) WHICH product of `a*b + c*d` is fused
+// depends on the surrounding code, so two builds of the same formulas differ by an ulp in one merge in a few thousand -
+// enough to tip the choice between two equal-area hull edges, or a threshold test three merges later.
+#pragma clang fp contract(off)
+
 constexpr int PP_KMAX = 128;
 constexpr int PP_THREADS = 256;
+constexpr int PP_TMAX = 64;
 constexpr int PP_WORK_BYTES = 65536;     // max(24 Pt x 256 threads, 32 DPt x 128 boxes)
 
 struct PPParams {
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(PP_THREADS) void postprocess_words_kernel(PPParams 
   // ---- text decode: the survivors' rows of the per-(box, step) argmax / maximum (text_argmax_kernel) into LDS (the
   // IoA matrix storage is free now)
   int* chr = reinterpret_cast<int*>(&ioa[0][0]);                  // [n][T]
-  float* prb = &ioa[0][0] + PP_KMAX * 32;                         // [n][T], T <= 32
+  float* prb = &ioa[0][0] + PP_KMAX * PP_TMAX;                    // [n][T], T <= PP_TMAX (2 x 128 x 64 <= 128 x 129 floats)
   const int n_fin = s_n;
   if (p.do_text) {
     for (int e = tid; e < n_fin * p.T; e += PP_THREADS) {
@@ -589,7 +597,7 @@ extern "C" int glass_postprocess_words(const float* boxes, const float* scores, 
   GLASS_CHECK_ARG(K == 0 || (boxes && scores && out_boxes && out_scores && out_polygons && out_src && out_char &&
                              out_text_score && out_text_len), "glass_postprocess_words: null pointer");
   GLASS_CHECK_ARG((text_arg == nullptr) == (text_max == nullptr), "glass_postprocess_words: text_arg and text_max go together");
-  GLASS_CHECK_ARG(!text_arg || (T > 0 && T <= 32), "glass_postprocess_words: text needs 0 < T <= 32");
+  GLASS_CHECK_ARG(!text_arg || (T > 0 && T <= PP_TMAX), "glass_postprocess_words: text needs 0 < T <= %d", PP_TMAX);
   PPParams p;
   p.boxes = boxes; p.scores = scores; p.counts = counts; p.text_arg = text_arg; p.text_max = text_max; p.scale_xy = scale_xy;
   p.N = N; p.K = K; p.T = text_arg ? T : 1;

@@ -915,8 +915,8 @@ def postprocess_words(boxes: torch.Tensor, scores: torch.Tensor, counts: torch.T
     opt = lambda t: c_void_p(_dev(t)) if t is not None else c_void_p(None)
     arg = mx = None
     if text is not None:
-        if T > 32:
-            raise ValueError(f"postprocess_words: T={T} decoding steps (max 32)")
+        if T > 64:
+            raise ValueError(f"postprocess_words: T={T} decoding steps (max 64)")
         arg, mx = text_argmax(text, counts)
     if scale_xy is not None:
         _f32c(scale_xy, "scale_xy")

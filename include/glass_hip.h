@@ -299,7 +299,7 @@ int glass_detections_finalize(const float* boxes, const float* scores, const flo
  * Outputs (padded to K, out_count[n] valid rows, in the reference's output order): boxes, scores,
  * polygons [N,K,4,2], out_src [N,K] source slot of each survivor (to gather other fields), out_char
  * [N,K,T] argmax character index per step, out_text_score [N,K], out_text_len [N,K] (characters before the
- * stop symbol).  K <= 128, T <= 32.                                                               */
+ * stop symbol).  K <= 128, T <= 64.                                                               */
 int glass_postprocess_words(const float* boxes, const float* scores, const int* counts, const int* text_arg,
                             const float* text_max, const float* scale_xy, int N, int K, int T,
                             const float* thresholds8_host, int stop_index, float* out_boxes, float* out_scores,

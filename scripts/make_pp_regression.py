@@ -1,8 +1,9 @@
 """Regression fixture of the word post-processor: inputs (padded detections) and the device kernel's outputs, written to
 gpurun_out/postprocess_words_regression.npz (copy to tests/golden/).  Provenance: the outputs were produced on an MI355X by the
-round-4 kernel, whose results are bit-identical (sha1 of all outputs on these very inputs, scripts/exp_pp_capture.py +
-profiles/r04_postprocess_latency.txt; and the round-3 kernel re-run on this fixture's inputs reproduces every output array exactly) to the round-1..3 kernel that tests/test_gpu_e_host_tail.py pins on the host restatement of
-the reference's PostProcessorAcademic.  Cases: the bench's detections of 8 images (set 0 of gpurun_out/pp_inputs.pt if present),
+round-4 kernel (compiled without FMA contraction, like the host restatement's numpy / torch-CPU arithmetic); the round-1..3 kernel that
+tests/test_gpu_e_host_tail.py pins on the host restatement of the reference's PostProcessorAcademic, re-built without contraction and
+re-run on this fixture's inputs, reproduces every output array exactly (profiles/r04_postprocess_latency.txt).
+Cases: the bench's detections of 8 images (set 0 of gpurun_out/pp_inputs.pt if present),
 dense scenes of 100 / 128 boxes with random scores (the score sort re-orders: both the recompute and the re-index path of the IoA
 matrix run), un-scaling, ragged counts including 0 and K."""
 import os, sys

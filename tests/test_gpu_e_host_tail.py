@@ -203,8 +203,9 @@ def test_device_postprocessor_equals_host_restatement_with_text():
 def test_postprocess_words_regression_fixture(golden_dir):
     """The word post-processor's outputs on committed detections (the bench's 8 images, dense scenes of 100 / 128 boxes with random
     scores, un-scaling, ragged counts) are EXACTLY those of the fixture (scripts/make_pp_regression.py: written by the round-4 kernel;
-    the round-3 kernel, pinned on the host restatement above, reproduces it bit for bit).  Guards the restructured merge loop:
-    queued near pairs, 8 lanes per merge, the NMS IoU re-indexed into the next iteration's IoA, bit-mask suppression."""
+    the round-3 kernel - pinned on the host restatement above - reproduces it bit for bit when it, too, is compiled without FMA
+    contraction, and so it does on the 160 scenes of scripts/fuzz_postprocess.py).  Guards the restructured merge loop: queued near
+    pairs, 8 lanes per merge, the NMS IoU re-indexed into the next iteration's IoA, bit-mask suppression."""
     from glass_amd.ops import native as K
     from glass_amd.utils.synth import pattern_text
     g = np.load(os.path.join(golden_dir, "postprocess_words_regression.npz"))
