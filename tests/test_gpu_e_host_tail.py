@@ -183,15 +183,16 @@ def test_device_postprocessor_equals_host_restatement_with_text():
         host = pp.host_call(mk())
         devr = pp(mk())
         assert len(host) == len(devr), (case, len(host), len(devr))
-        # measured (printed above): <= 5e-4 px on coordinates up to 1400 (a few fp32 ulps, from the 1-ulp sin/cos
-        # differences between torch-CPU and the device through chains of merges); asserted at 2e-3 px (round 1: 0.5 px)
+        # measured (printed below): boxes EXACT in 5 of the 7 scenes, <= 6.1e-5 px in the others, polygons <= 9.2e-5 px (the 1-ulp
+        # sin / cos differences between torch-CPU and the device) since the kernel is compiled without FMA contraction (round 4; with
+        # contraction: up to 4.9e-4 px); asserted at 5e-4 px (round 1: 0.5 px, rounds 2-3: 2e-3)
         db = np.abs(devr.pred_boxes.tensor.cpu().numpy() - host.pred_boxes.tensor.cpu().numpy())
         dp = np.abs(devr.pred_polygons.cpu().numpy() - host.pred_polygons.cpu().numpy())
         print(f"[post-processor device vs host] case {case}: n = {len(host)}, max |dbox| = {db.max() if db.size else 0:.3e}, "
               f"max |dpolygon| = {dp.max() if dp.size else 0:.3e} px")
-        np.testing.assert_allclose(devr.pred_boxes.tensor.cpu().numpy(), host.pred_boxes.tensor.cpu().numpy(), rtol=0, atol=2e-3)
+        np.testing.assert_allclose(devr.pred_boxes.tensor.cpu().numpy(), host.pred_boxes.tensor.cpu().numpy(), rtol=0, atol=5e-4)
         np.testing.assert_allclose(devr.scores.cpu().numpy(), host.scores.cpu().numpy(), atol=1e-6)
-        np.testing.assert_allclose(devr.pred_polygons.cpu().numpy(), host.pred_polygons.cpu().numpy(), rtol=0, atol=2e-3)
+        np.testing.assert_allclose(devr.pred_polygons.cpu().numpy(), host.pred_polygons.cpu().numpy(), rtol=0, atol=5e-4)
         assert torch.equal(devr.orientations.cpu(), host.orientations.cpu())
         assert torch.equal(devr.pred_text_prob.cpu(), host.pred_text_prob.cpu())
         from glass_amd.postprocess.post_processor_academic import get_instances_text
@@ -220,6 +221,41 @@ def test_postprocess_words_regression_fixture(golden_dir):
             assert np.array_equal(v.cpu().numpy(), g[f"{name}/out_{k}"]), (name, k)
         assert int(o["count"].sum()) > 0
         print(f"[post-processor regression] {name}: kept {o['count'].tolist()} (exact)")
+
+
+def test_postprocess_words_with_50_character_words():
+    """T = 51 decoding steps (MAX_WORD_LENGTH 50, the reference's mask-head default; the shipped recognizer configs use 25): the
+    survivors' characters, word scores and lengths against numpy on well-separated boxes (nothing merges)."""
+    from glass_amd.ops import native as K
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    N, KK, T, C, stop = 2, 6, 51, 97, 94
+    boxes = torch.tensor([[100.0 + 150 * k, 80.0 + 60 * (k % 2), 90.0, 24.0, 5.0 * k] for k in range(KK)]).repeat(N, 1, 1)
+    scores = torch.rand((N, KK), generator=g) * 0.5 + 0.5
+    text = torch.softmax(torch.randn((N, KK, T, C), generator=g) * 8, -1)
+    text[:, :, 40, :] = 0.0
+    text[:, :, 40, stop] = 1.0                                    # a stop symbol at step 40 ...
+    text[0, 1, :, stop] = 0.0                                     # ... except for one word that never stops
+    text[0, 1, 40, 3] = 1.0
+    text[0, 1] = text[0, 1] / text[0, 1].sum(-1, keepdim=True)
+    cnt = torch.tensor([KK, KK - 2], dtype=torch.int32)
+    thr = [2.0, 0.15, 0.25, 0.3, 0.35, 15.0, 0.01, 0.0]
+    o = K.postprocess_words(boxes.to(dev), scores.to(dev), cnt.to(dev), text.to(dev), None, thr, stop)
+    assert o["count"].tolist() == [KK, KK - 2]
+    mx, arg = text.max(dim=3)
+    for n in range(N):
+        for d in range(int(o["count"][n])):
+            k = int(o["src"][n, d])
+            assert torch.equal(o["char"][n, d].cpu(), arg[n, k].to(torch.int32))
+            stops = (arg[n, k] == stop).nonzero()
+            L = int(stops[0]) if len(stops) else T
+            assert int(o["text_len"][n, d]) == L
+            ref = np.float32(1.0)
+            for t in range(min(L + 1, T)):
+                ref = np.float32(ref * mx[n, k, t].numpy())
+            np.testing.assert_allclose(float(o["text_score"][n, d]), float(ref), rtol=1e-6)
+    with pytest.raises(ValueError):
+        K.postprocess_words(boxes.to(dev), scores.to(dev), cnt.to(dev), torch.zeros((N, KK, 65, C), device=dev), None, thr, stop)
 
 
 def test_text_argmax_matches_torch_max():
