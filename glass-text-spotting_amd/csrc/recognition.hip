@@ -88,21 +88,32 @@ __global__ __launch_bounds__(256) void gc_attention_kernel(float* __restrict__ x
 
   // phase 1: mask logits. A wavefront covers one position per iteration: lane l holds channels
   // 4l..4l+3 and 256+4l..; a head is 64 channels = 16 lanes -> 4-step shuffle reduction.
+  // (8 positions = 16 independent 16-byte loads per lane in flight per trip: the slab streams from HBM, and one position per
+  //  trip - the shuffles and the LDS store keep the compiler from overlapping trips - made this phase 64 serial round trips)
   const float4 wm = *reinterpret_cast<const float4*>(w_mask + ((lane * 4) & 63));
   const float bm = b_mask[0];
-  for (int pos = wave; pos < GC_HW; pos += 4) {
-    const float4 a = *reinterpret_cast<const float4*>(x + (long)pos * GC_C + lane * 4);
-    const float4 b = *reinterpret_cast<const float4*>(x + (long)pos * GC_C + 256 + lane * 4);
-    float sa = a.x * wm.x + a.y * wm.y + a.z * wm.z + a.w * wm.w;
-    float sb = b.x * wm.x + b.y * wm.y + b.z * wm.z + b.w * wm.w;
+  constexpr int GC_U1 = 8;
+  static_assert(GC_HW % (4 * GC_U1) == 0, "phase 1 unroll");
+  for (int pos0 = wave; pos0 < GC_HW; pos0 += 4 * GC_U1) {
+    float4 a[GC_U1], b[GC_U1];
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-      sa += __shfl_xor(sa, off);
-      sb += __shfl_xor(sb, off);
+    for (int i = 0; i < GC_U1; ++i) {
+      a[i] = *reinterpret_cast<const float4*>(x + (long)(pos0 + 4 * i) * GC_C + lane * 4);
+      b[i] = *reinterpret_cast<const float4*>(x + (long)(pos0 + 4 * i) * GC_C + 256 + lane * 4);
     }
-    if ((lane & 15) == 0) {
-      prob[lane >> 4][pos] = sa + bm;
-      prob[4 + (lane >> 4)][pos] = sb + bm;
+#pragma unroll
+    for (int i = 0; i < GC_U1; ++i) {
+      float sa = a[i].x * wm.x + a[i].y * wm.y + a[i].z * wm.z + a[i].w * wm.w;
+      float sb = b[i].x * wm.x + b[i].y * wm.y + b[i].z * wm.z + b[i].w * wm.w;
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+      }
+      if ((lane & 15) == 0) {
+        prob[lane >> 4][pos0 + 4 * i] = sa + bm;
+        prob[4 + (lane >> 4)][pos0 + 4 * i] = sb + bm;
+      }
     }
   }
   __syncthreads();
@@ -124,23 +135,47 @@ __global__ __launch_bounds__(256) void gc_attention_kernel(float* __restrict__ x
   {
     float c0 = 0.f, c1 = 0.f;
     const int h0 = tid >> 6, h1 = 4 + (tid >> 6);
-    for (int pos = 0; pos < GC_HW; ++pos) {
-      c0 += x[(long)pos * GC_C + tid] * prob[h0][pos];
-      c1 += x[(long)pos * GC_C + 256 + tid] * prob[h1][pos];
+    constexpr int GC_U3 = 16;                                   // 32 independent loads per thread in flight; same summation order
+    for (int pos0 = 0; pos0 < GC_HW; pos0 += GC_U3) {
+      float v0[GC_U3], v1[GC_U3];
+#pragma unroll
+      for (int i = 0; i < GC_U3; ++i) {
+        v0[i] = x[(long)(pos0 + i) * GC_C + tid];
+        v1[i] = x[(long)(pos0 + i) * GC_C + 256 + tid];
+      }
+#pragma unroll
+      for (int i = 0; i < GC_U3; ++i) {
+        c0 += v0[i] * prob[h0][pos0 + i];
+        c1 += v1[i] * prob[h1][pos0 + i];
+      }
     }
     ctx[tid] = c0;
     ctx[256 + tid] = c1;
   }
   __syncthreads();
   // phase 4a: hid = W1 ctx + b1 (256 x 512): each wavefront takes rows wave, wave+4, ...
-  for (int j = wave; j < GC_P; j += 4) {
-    const float4 wa = *reinterpret_cast<const float4*>(w1 + (long)j * GC_C + lane * 4);
-    const float4 wb = *reinterpret_cast<const float4*>(w1 + (long)j * GC_C + 256 + lane * 4);
+  // (8 rows per trip: the weight rows come from L2 and the reduction after each row kept one row in flight - 64 serial L2
+  //  round trips per wavefront here, 128 in phase 4b)
+  {
+    constexpr int GC_U4 = 8;
+    static_assert(GC_P % (4 * GC_U4) == 0 && GC_C % (4 * GC_U4) == 0, "phase 4 unroll");
     const float4 ca = *reinterpret_cast<const float4*>(ctx + lane * 4);
     const float4 cb = *reinterpret_cast<const float4*>(ctx + 256 + lane * 4);
-    float s = wa.x * ca.x + wa.y * ca.y + wa.z * ca.z + wa.w * ca.w + wb.x * cb.x + wb.y * cb.y + wb.z * cb.z + wb.w * cb.w;
-    s = wave_sum(s);
-    if (lane == 0) hid[j] = s + b1[j];
+    for (int j0 = wave; j0 < GC_P; j0 += 4 * GC_U4) {
+      float4 wa[GC_U4], wb[GC_U4];
+#pragma unroll
+      for (int i = 0; i < GC_U4; ++i) {
+        wa[i] = *reinterpret_cast<const float4*>(w1 + (long)(j0 + 4 * i) * GC_C + lane * 4);
+        wb[i] = *reinterpret_cast<const float4*>(w1 + (long)(j0 + 4 * i) * GC_C + 256 + lane * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < GC_U4; ++i) {
+        float s = wa[i].x * ca.x + wa[i].y * ca.y + wa[i].z * ca.z + wa[i].w * ca.w + wb[i].x * cb.x + wb[i].y * cb.y + wb[i].z * cb.z +
+                  wb[i].w * cb.w;
+        s = wave_sum(s);
+        if (lane == 0) hid[j0 + 4 * i] = s + b1[j0 + 4 * i];
+      }
+    }
   }
   __syncthreads();
   // LayerNorm over the 256 hidden values (biased variance, eps 1e-5) + ReLU
@@ -161,23 +196,36 @@ __global__ __launch_bounds__(256) void gc_attention_kernel(float* __restrict__ x
   }
   __syncthreads();
   // phase 4b: t = W2 hid + b2 (512 x 256) -> reuse ctx[] for t
-  for (int c = wave; c < GC_C; c += 4) {
-    const float4 wv = *reinterpret_cast<const float4*>(w2 + (long)c * GC_P + lane * 4);
+  {
+    constexpr int GC_U4 = 8;
     const float4 hv = *reinterpret_cast<const float4*>(hid + lane * 4);
-    float s = wv.x * hv.x + wv.y * hv.y + wv.z * hv.z + wv.w * hv.w;
-    s = wave_sum(s);
-    if (lane == 0) ctx[c] = s + b2[c];
+    for (int c0 = wave; c0 < GC_C; c0 += 4 * GC_U4) {
+      float4 wv[GC_U4];
+#pragma unroll
+      for (int i = 0; i < GC_U4; ++i) wv[i] = *reinterpret_cast<const float4*>(w2 + (long)(c0 + 4 * i) * GC_P + lane * 4);
+#pragma unroll
+      for (int i = 0; i < GC_U4; ++i) {
+        float s = wv[i].x * hv.x + wv[i].y * hv.y + wv[i].z * hv.z + wv[i].w * hv.w;
+        s = wave_sum(s);
+        if (lane == 0) ctx[c0 + 4 * i] = s + b2[c0 + 4 * i];
+      }
+    }
   }
   __syncthreads();
   // phase 5: x += t (broadcast over positions), float4 streaming
   {
     const int c4 = tid & 127;           // 128 float4 per position
     const float4 t = *reinterpret_cast<const float4*>(ctx + c4 * 4);
-    for (int pos = tid >> 7; pos < GC_HW; pos += 2) {
-      float4* px = reinterpret_cast<float4*>(x + (long)pos * GC_C) + c4;
-      float4 v = *px;
-      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-      *px = v;
+    constexpr int GC_U5 = 16;
+    for (int pos0 = tid >> 7; pos0 < GC_HW; pos0 += 2 * GC_U5) {
+      float4 v[GC_U5];
+#pragma unroll
+      for (int i = 0; i < GC_U5; ++i) v[i] = *(reinterpret_cast<const float4*>(x + (long)(pos0 + 2 * i) * GC_C) + c4);
+#pragma unroll
+      for (int i = 0; i < GC_U5; ++i) {
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+        *(reinterpret_cast<float4*>(x + (long)(pos0 + 2 * i) * GC_C) + c4) = v[i];
+      }
     }
   }
 }
