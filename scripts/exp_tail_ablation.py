@@ -1,5 +1,5 @@
 """Timing ablation (wrong results, timing only): how much of the pipelined step do the recurrent launch chains cost?
-    GLASS_ABL_TAIL=lstm|decoder|gc|all python scripts/exp_tail_ablation.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras
+    GLASS_ABL_TAIL=lstm|decoder|gc|all|skinny python scripts/exp_tail_ablation.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras
 runs bench.py with the named ops replaced by an allocation of their output (no launches)."""
 import os, runpy, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,5 +17,13 @@ if what in ("decoder", "all"):
     K.attention_decode = _no_dec
 if what in ("gc", "all"):
     K.gc_attention_inplace = lambda x, *a, **k: x
+if what in ("skinny",):                    # the few-workgroup, long-K layers: box predictor (Cout 11, K 2048) -> a slice of its input
+    _lin = K.linear
+    def _lin_abl(x, w, bias=None, relu=0, out=None, out_dtype=None, precision=None):
+        n = (w.raw if isinstance(w, K.ConvWeight) else w).shape[0]
+        if n <= 16 and out is None:
+            return x[:, :n].contiguous()
+        return _lin(x, w, bias, relu, out, out_dtype, precision)
+    K.linear = _lin_abl
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
