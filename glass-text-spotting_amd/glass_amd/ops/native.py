@@ -461,8 +461,13 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     # ahead for every Cin >= 256 (256->1024 and 256->256 x1.08, 1024->256 x1.09, 512->128 x1.11, 512->2048 @32x32 x1.07;
     # behind on 128->512 x0.92 and 64->256 x0.87), but routing the narrow / small ones to it (Cout 128, 8192-pixel maps)
     # LOWERS the end-to-end rate: 274.1 images/s with this rule, 271 without the kernel, 267 with "Cin >= 256, >= 8192
-    # pixels" (three alternating runs each, same box)
-    if (winograd is None and rt.pw and KH == 1 and KW == 1 and (rt.pw == "all" or (Cin >= 256 and Cout >= 256 and N * Ho * Wo >= 16384))
+    # pixels" (three alternating runs each, same box).  Round 4: the res5-size layers with BOTH channel counts >= 512 (8192
+    # pixels at batch 8: 2048->512, 512->2048 +res, 1024->2048 s2, 1024->512 s2) are 7-13 % faster on it and worth +0.2 % end
+    # to end (five alternating runs: 280.3 vs 279.7); the Cout = 128 layers still are not (279.5), and below 8192 pixels the
+    # per-workgroup weight stream is not amortised (batch 2: 2-4x SLOWER than the direct kernel).
+    px = N * Ho * Wo
+    if (winograd is None and rt.pw and KH == 1 and KW == 1 and
+            (rt.pw == "all" or (Cin >= 256 and Cout >= 256 and px >= 16384) or (Cin >= 512 and Cout >= 512 and px >= 8192))
             and lib().glass_pointwise_supported(ctypes.byref(d))):
         return launch("glass_conv1x1_pointwise_nhwc", "pointwise", x, _packed(w, wt, "pw"))
     use_wino = rt.winograd if winograd is None else winograd
