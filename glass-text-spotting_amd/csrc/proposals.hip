@@ -45,6 +45,45 @@ struct NmsParams {
   float* out_boxes; float* out_scores; int* out_index; int* out_count;
 };
 
+// the early exit of rotated_iou (rotated_iou.h: circumscribed circles disjoint -> IoU exactly 0), as a predicate of its own
+__device__ __forceinline__ bool rbox_far_apart(const RBox& a, const RBox& b) {
+#pragma clang fp contract(off)
+  const float dx = a.cx - b.cx, dy = a.cy - b.cy;
+  const float rr = 0.5f * (sqrtf(a.w * a.w + a.h * a.h) + sqrtf(b.w * b.w + b.h * b.h));
+  return dx * dx + dy * dy > rr * rr * 1.001f + 1e-2f;
+}
+
+// `total` box pairs, pair pr -> (i, j) by `decode`; the pairs that are not far apart - the ones that run the polygon clipping,
+// whose point lists live in scratch - are collected per wavefront (ballot compaction, 128 entries each) and evaluated 64 at a
+// time with every lane busy, instead of by whichever lanes of a round happen to hold one (postprocess.hip: pp_for_pairs).
+template <class Decode, class Far, class Heavy>
+__device__ __forceinline__ void nms_for_pairs(int total, unsigned short* queue, Decode decode, Far far, Heavy heavy) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int qn = 0;                                                       // (wavefront-uniform)
+  for (int base = threadIdx.x & ~63; base < total; base += NMS_THREADS) {
+    const int pr = base + lane;
+    int i = 0, j = 0;
+    bool near = false;
+    if (pr < total) {
+      decode(pr, i, j);
+      near = !far(i, j);
+    }
+    const unsigned long long m = __ballot(near);
+    if (near) queue[qn + __popcll(m & below)] = (unsigned short)((i << 6) | j);
+    qn += __popcll(m);
+    if (qn >= 64) {
+      qn -= 64;
+      const int e = queue[qn + lane];
+      heavy(e >> 6, e & 63);
+    }
+  }
+  if (lane < qn) {
+    const int e = queue[lane];
+    heavy(e >> 6, e & 63);
+  }
+}
+
 __global__ __launch_bounds__(NMS_THREADS) void nms_select_kernel(NmsParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   // carve: sorted composites [npad] u64 | kept boxes | chunk boxes | masks
@@ -61,6 +100,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_select_kernel(NmsParams p) {
   __shared__ float red_max[NMS_THREADS / 64], red_min[NMS_THREADS / 64];
   __shared__ float s_span;
   __shared__ int s_nvalid, s_nkept, s_stop;
+  __shared__ float cbox[64][5], cscore[64];      // the chunk's (clipped) boxes and scores as they go to the outputs
+  __shared__ int ckept[64];                      // output slot of a chunk candidate, -1: suppressed
+  __shared__ unsigned short pair_queue[NMS_THREADS / 64][128];
 
   const float* boxes = p.boxes + (long)n * S * 5;
   const float* scores = p.scores + (long)n * S;
@@ -150,36 +192,34 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_select_kernel(NmsParams p) {
         const float off = cat ? (float)cat[s] * span : 0.f;
         chunk[threadIdx.x] = make_rbox(b[0] + off, b[1] + off, b[2], b[3], b[4]);
         cslot[threadIdx.x] = s;
+#pragma unroll
+        for (int e = 0; e < 5; ++e) cbox[threadIdx.x][e] = b[e];
+        cscore[threadIdx.x] = scores[s];
       }
     }
     __syncthreads();
     const int nk = s_nkept;
-    // (a) candidates vs already kept boxes
-    for (int pr = threadIdx.x; pr < csize * nk; pr += blockDim.x) {
-      const int j = pr / nk, i = pr - j * nk;
-      if (rotated_iou(kept[i], chunk[j]) >= p.nms_thresh) csup[j] = 1;
-    }
+    unsigned short* queue = pair_queue[threadIdx.x >> 6];
+    // (a) candidates vs already kept boxes (i: kept box < 1024, j: candidate of the chunk)
+    nms_for_pairs(csize * nk, queue, [&](int pr, int& i, int& j) { j = pr / nk; i = pr - j * nk; },
+                  [&](int i, int j) { return rbox_far_apart(kept[i], chunk[j]); },
+                  [&](int i, int j) { if (rotated_iou(kept[i], chunk[j]) >= p.nms_thresh) csup[j] = 1; });
     // (b) intra-chunk pairs i < j
-    for (int pr = threadIdx.x; pr < csize * csize; pr += blockDim.x) {
-      const int i = pr / csize, j = pr - i * csize;
-      if (i < j && rotated_iou(chunk[i], chunk[j]) >= p.nms_thresh) atomicOr(&cmask[i], 1ull << j);
-    }
+    nms_for_pairs(csize * csize, queue, [&](int pr, int& i, int& j) { i = pr / csize; j = pr - i * csize; },
+                  [&](int i, int j) { return i >= j || rbox_far_apart(chunk[i], chunk[j]); },
+                  [&](int i, int j) { if (rotated_iou(chunk[i], chunk[j]) >= p.nms_thresh) atomicOr(&cmask[i], 1ull << j); });
     __syncthreads();
-    // (c) serial resolve inside the chunk
+    // (c) serial resolve inside the chunk: LDS only (the survivors' output rows - which used to be re-read from global memory
+    // inside this one-thread loop, a dependent round trip per kept box - are written by 64 threads afterwards)
     if (threadIdx.x == 0) {
       u64 sup = 0;
       int kcount = nk;
       for (int i = 0; i < csize; ++i) {
+        ckept[i] = -1;
         if (csup[i] || ((sup >> i) & 1ull)) continue;
-        if (kcount >= keep_cap) { s_stop = 1; break; }
+        if (kcount >= keep_cap) { s_stop = 1; for (int j = i + 1; j < csize; ++j) ckept[j] = -1; break; }
         kept[kcount] = chunk[i];
-        const int s = cslot[i];
-        float b[5];
-        load_box(s, b);
-        float* ob = p.out_boxes + ((long)n * p.post_topk + kcount) * 5;
-        ob[0] = b[0]; ob[1] = b[1]; ob[2] = b[2]; ob[3] = b[3]; ob[4] = b[4];
-        p.out_scores[(long)n * p.post_topk + kcount] = scores[s];
-        p.out_index[(long)n * p.post_topk + kcount] = s;
+        ckept[i] = kcount;
         ++kcount;
         sup |= cmask[i];
       }
@@ -187,6 +227,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_select_kernel(NmsParams p) {
       s_nkept = kcount;
     }
     __syncthreads();
+    if ((int)threadIdx.x < csize && ckept[threadIdx.x] >= 0) {
+      const long o = (long)n * p.post_topk + ckept[threadIdx.x];
+#pragma unroll
+      for (int e = 0; e < 5; ++e) p.out_boxes[o * 5 + e] = cbox[threadIdx.x][e];
+      p.out_scores[o] = cscore[threadIdx.x];
+      p.out_index[o] = cslot[threadIdx.x];
+    }
     if (s_stop) break;
   }
   if (threadIdx.x == 0) p.out_count[n] = s_nkept;
@@ -215,7 +262,7 @@ extern "C" int glass_rotated_nms_select(const float* boxes, const float* scores,
   p.score_thresh = score_thresh; p.nms_thresh = nms_thresh; p.post_topk = post_topk; p.flags = flags;
   p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_index = out_index; p.out_count = out_count;
   static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_select_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);      // S <= 8192: 64 KB of sort keys + 26 KB of boxes + masks (the kernel's static LDS is ~6.5 KB)
   if (attr_rc != 0) {
     glass_set_error("glass_rotated_nms_select: cannot raise the dynamic LDS limit (hip error %d)", attr_rc);
     return GLASS_EHIP;
