@@ -10,21 +10,7 @@
 // on 16x16x4 fp32 MFMA tiles).  Weights stream from L2 in a k-blocked layout
 // (packed[k/4][row][4]) so that the 64 lanes of a wavefront read 1 KiB contiguous per load; reductions (softmax,
 // LayerNorm, attention energies) are wavefront shuffle reductions (64 lanes) + one LDS hop across the 4 wavefronts.
-#include "common.h"
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-  return v;
-}
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp/rcp (|err| < 2e-7 absolute; saturates cleanly)
-__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
+#include "recognition_common.h"
 
 // acc[g][r] += sum_k W[g*gstride + u][k] * vec[r][k] for one output unit `u` per thread, weights in the
 // k-blocked layout (w4[k4 * rows_total + row] = 4 consecutive k of `row`).  L2 latency (~300 ns) is far
@@ -254,8 +240,6 @@ constexpr int LSTM_HD = 256;
 constexpr int LS_RB = 16;   // RoIs per workgroup (= the N of a 16x16x4 MFMA)
 constexpr int LS_UB = 32;   // hidden units per workgroup
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 // C[16 rows][16 RoIs] += W[row0 .. row0+16)[0..K) . hs[roi][0..K)^T on v_mfma_f32_16x16x4_f32.
 // W is the plain row-major [rows][K] matrix (nn.LSTM / nn.GRU layout).  Lane l = (row r = l&15,
 // k-quarter q = l>>4) loads 16 bytes = W[row0+r][16S + 4q .. +3] and hs[l&15][16S + 4q .. +3]; MFMA c of
@@ -320,11 +304,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
       const int u = ub * LS_UB + ul;
       const long idx = ((long)(r0 + r) * 2 + dir) * LSTM_HD + u;
       const float* xr = xg + (((long)(r0 + r) * T + t) * 2 + dir) * (4 * LSTM_HD) + u;
-      const float ig = sigmoidf_(xr[0] + gates[r][ul]), fg = sigmoidf_(xr[LSTM_HD] + gates[r][LS_UB + ul]);
-      const float gg = tanhf(xr[2 * LSTM_HD] + gates[r][2 * LS_UB + ul]), og = sigmoidf_(xr[3 * LSTM_HD] + gates[r][3 * LS_UB + ul]);
-      const float c = fg * c_state[idx] + ig * gg;
-      c_state[idx] = c;
-      const float hn = og * tanhf(c);
+      const LstmCell cell = lstm_cell(xr[0] + gates[r][ul], xr[LSTM_HD] + gates[r][LS_UB + ul], xr[2 * LSTM_HD] + gates[r][2 * LS_UB + ul],
+                                      xr[3 * LSTM_HD] + gates[r][3 * LS_UB + ul], c_state[idx]);
+      c_state[idx] = cell.c;
+      const float hn = cell.h;
       h_next[idx] = hn;
       out[((long)(r0 + r) * T + t) * (2 * LSTM_HD) + dir * LSTM_HD + u] = hn;
     }

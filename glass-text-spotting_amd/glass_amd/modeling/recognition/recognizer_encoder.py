@@ -2,7 +2,8 @@
 
 Mirrors reference glass/modeling/recognition/recognizer_encoder.py:101-144.  The input
 projections of both directions are one MFMA GEMM ([R*T,256] x [256,2048]); the recurrence is one ABI call per
-layer (glass_bilstm_recurrence: one chip-wide kernel per time step - a persistent workgroup per RoI group was measured 3x slower).
+layer: glass_bilstm_recurrence_persistent (ONE launch: W_hh resident in registers, h_t handed between the 8 workgroups of a
+16-RoI chain inside the launch) or, with Routing.rnn == "steps", glass_bilstm_recurrence (one chip-wide kernel per time step).
 """
 from __future__ import annotations
 
@@ -46,7 +47,7 @@ class BiLSTMBlockV2(InferenceModule):
         R, T, _ = x.shape
         for L in self.layers:
             xg = K.linear(x.view(R * T, -1), L["w_ih"], L["b"]).view(R, T, 2, 4 * self.hidden)
-            rec = K.bilstm_recurrence(xg, L["w_hh"], self.hidden)
+            rec = K.bilstm_recurrence(xg, L["w_hh"], self.hidden, mode=K.routing_of(L["w_ih"]).rnn)
             x = K.linear(rec.view(R * T, -1), L["lin_w"], L["lin_b"]).view(R, T, -1)
         return x
 

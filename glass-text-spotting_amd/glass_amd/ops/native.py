@@ -85,6 +85,16 @@ def conv_out_size(H, W, KH, KW, stride, padding):
 _PRECISIONS = ("fp32", "fp16", "fp16s")
 
 
+def _parse_rnn(v):
+    if v in ("steps", "persistent") or isinstance(v, tuple):
+        return v
+    try:
+        nd, ng = (int(t) for t in str(v).split("x"))
+    except ValueError:
+        raise GlassLibraryError(f"unknown recurrent routing {v!r} (steps | persistent | 2x1 | 2x2 | 1x1)") from None
+    return (nd, ng)
+
+
 class Routing:
     """Which kernel a conv / linear launch takes, as VALUES that travel with the layer (no global state, re-entrant
     per model): a model builds one `Routing` at construction (environment variables GLASS_* give the defaults, `MODEL.
@@ -101,13 +111,17 @@ class Routing:
       stem        the fused 7x7 conv + ReLU + max-pool kernel of the ResNet stem (GLASS_BACKBONE_STEM=0: two launches)
       ragged      maps of width 4 k + 1 on the F(4x4) kernel: full tile columns there + the last pixel column as a strip
                   convolution (GLASS_W43_RAGGED=0: a whole extra tile column, as in rounds 2-3)
+      rnn         the recurrent encoder: (directions, RoI groups) a workgroup of the one-launch-per-layer BiLSTM kernel
+                  interleaves - "1x1" (default: shortest chain, 3 % off the one-step-at-a-time latency), "2x1", "2x2",
+                  "persistent" = the library's default - or "steps" (GLASS_RNN=steps: one launch per time step,
+                  csrc/recognition.hip); outputs are bit-identical
       pooled_fusion  P2P3Fusion's two 1x1 convolutions AFTER the recognizer pooler (on the pooled bins) instead of on the whole
                   p2 / p3 maps - RoIAlign and the fusion are both linear (GLASS_POOLED_FUSION=0: whole-map fusion, then pool)"""
-    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion")
+    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion", "rnn")
 
     def __init__(self, precision: Optional[str] = None, winograd: Optional[bool] = None, f43: Optional[bool] = None, pw=None,
                  h16: Optional[bool] = None, local_stem: Optional[bool] = None, stem: Optional[bool] = None,
-                 ragged: Optional[bool] = None, pooled_fusion: Optional[bool] = None):
+                 ragged: Optional[bool] = None, pooled_fusion: Optional[bool] = None, rnn=None):
         e = os.environ.get
         self.precision = precision or e("GLASS_CONV_PRECISION", "fp32")
         if self.precision not in _PRECISIONS:
@@ -120,6 +134,7 @@ class Routing:
         self.stem = (e("GLASS_BACKBONE_STEM", "1") != "0") if stem is None else bool(stem)
         self.ragged = (e("GLASS_W43_RAGGED", "1") != "0") if ragged is None else bool(ragged)
         self.pooled_fusion = (e("GLASS_POOLED_FUSION", "1") != "0") if pooled_fusion is None else bool(pooled_fusion)
+        self.rnn = _parse_rnn(e("GLASS_RNN", "1x1")) if rnn is None else _parse_rnn(rnn)
 
     def replace(self, **kw) -> "Routing":
         r = Routing.__new__(Routing)
@@ -802,12 +817,23 @@ def mean_over_h(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def bilstm_recurrence(xg: torch.Tensor, w_hh_packed: torch.Tensor, hidden: int) -> torch.Tensor:
-    """xg [R,T,2,4*Hd] -> out [R,T,2*Hd]."""
+def bilstm_recurrence(xg: torch.Tensor, w_hh_packed: torch.Tensor, hidden: int, mode=None) -> torch.Tensor:
+    """xg [R,T,2,4*Hd] -> out [R,T,2*Hd].  `mode`: "steps" (one launch per time step, glass_bilstm_recurrence), "persistent" or
+    (dirs, groups) per workgroup (ONE launch per layer, glass_bilstm_recurrence_persistent; bit-identical outputs); None = the
+    raw-tensor default routing's `rnn`."""
     _f32c(xg, "xg"); _f32c(w_hh_packed, "w_hh_packed")
     R, T = xg.shape[0], xg.shape[1]
     out = torch.empty((R, T, 2 * hidden), dtype=torch.float32, device=xg.device)
     if R == 0:
+        return out
+    mode = _DEFAULT.rnn if mode is None else mode
+    if mode != "steps":
+        nd, ng = (0, 0) if mode == "persistent" else mode
+        nbytes = int(lib().glass_bilstm_persistent_workspace_bytes(R, hidden))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=xg.device)
+        check(lib().glass_bilstm_recurrence_persistent(c_void_p(_dev(xg)), c_void_p(_dev(w_hh_packed)), c_void_p(_dev(out)), R, T,
+                                                       hidden, int(nd), int(ng), c_void_p(_dev(ws)), ctypes.c_int64(nbytes),
+                                                       c_void_p(stream_handle())), "glass_bilstm_recurrence_persistent")
         return out
     nbytes = int(lib().glass_bilstm_workspace_bytes(R, hidden))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=xg.device)
@@ -815,6 +841,14 @@ def bilstm_recurrence(xg: torch.Tensor, w_hh_packed: torch.Tensor, hidden: int) 
                                         c_void_p(_dev(ws)), ctypes.c_int64(nbytes), c_void_p(stream_handle())),
           "glass_bilstm_recurrence")
     return out
+
+
+def recurrence_status(reset: bool = True) -> int:
+    """the device's sticky hand-off status (synchronises the device): 0 = every in-kernel wait of the persistent recurrent
+    kernels was met; bit 0 / bit 1 = an LSTM / decoder hand-off gave up (outputs of that call are garbage)"""
+    st = ctypes.c_int(0)
+    check(lib().glass_recurrence_status(ctypes.byref(st), int(bool(reset))), "glass_recurrence_status")
+    return int(st.value)
 
 
 def attention_decode(x: torch.Tensor, xproj: torch.Tensor, weights: dict, roi_image: torch.Tensor, num_images: int,

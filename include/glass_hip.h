@@ -373,6 +373,19 @@ int glass_paste_rotated_masks(const float* masks, const float* boxes, int R, int
 int64_t glass_bilstm_workspace_bytes(int R, int Hd);
 int glass_bilstm_recurrence(const float* xg, const float* w_hh, float* out, int R, int T, int Hd, void* workspace,
                             int64_t workspace_bytes, glass_stream_t stream);
+/* The same recurrence as ONE launch per layer (csrc/recurrent_persistent.hip; same reference lines, same arguments, outputs
+ * bit-identical to glass_bilstm_recurrence): W_hh resident in registers, h_t handed between the 8 workgroups of a
+ * (16-RoI group, direction) chain inside the launch as 8-byte {step tag, value} device-scope granules.
+ * dirs_per_workgroup / groups_per_workgroup: how many independent chains a workgroup interleaves - (2,1) (0,0 = default:
+ * both directions of one RoI group, 8 workgroups per 16 RoIs), (2,2) or (1,1).  `workspace` (16-byte aligned, >=
+ * glass_bilstm_persistent_workspace_bytes()) is zeroed by the call.  Every in-kernel wait is bounded; a wait that gave up
+ * raises bit 0 of the device's sticky status word, read (after a device synchronise) with glass_recurrence_status
+ * (bit 1: glass_attention_decode_persistent).                                                                  */
+int64_t glass_bilstm_persistent_workspace_bytes(int R, int Hd);
+int glass_bilstm_recurrence_persistent(const float* xg, const float* w_hh, float* out, int R, int T, int Hd,
+                                       int dirs_per_workgroup, int groups_per_workgroup, void* workspace,
+                                       int64_t workspace_bytes, glass_stream_t stream);
+int glass_recurrence_status(int* status_out, int reset);
 
 /* ------------------------------------------------------------------ attention decoder
  * Greedy additive-attention GRU decoder (AttentionRecognitionHead.sample,
