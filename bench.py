@@ -108,6 +108,10 @@ class ConvMeter:
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 3) // 4) * (y.shape[2] // 4) * 36 * cout * cin + \
                     2.0 * y.shape[0] * y.shape[1] * cout * 6 * cin
                 path = "winograd43"
+            elif path in ("winograd128r", "winogradr"):  # odd width: F(2x2) on the W // 2 full tile columns + the last column direct (3 x 2 taps)
+                ex = 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * (y.shape[2] // 2) * 16 * cout * cin + \
+                    2.0 * y.shape[0] * y.shape[1] * cout * 6 * cin
+                path = path[:-1]
             elif path == "winograd43":                  # F(4x4,3x3): 36 MACs per (ceil(H/4) x ceil(W/4)) tile, channel pair
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 3) // 4) * ((y.shape[2] + 3) // 4) * 36 * cout * cin
             elif path.startswith("winograd"):           # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair

@@ -35,6 +35,8 @@ struct ConvParams {
   unsigned x_bytes, w_bytes;      // buffer sizes for the bounds-checked load paths (0: tensors too large)
   unsigned y_bytes, r_bytes;      // output / residual spans of the vector epilogue (it is enabled only if they fit 31 bits)
   unsigned magic_cin, magic_kw;   // floor(2^32 / Cin), floor(2^32 / KW) for the per-thread tap decode (MODE 2)
+  int ksplit;                     // > 1: split-K launch (glass_conv2d_nhwc_splitk, MODE 1 only): blockIdx.y = k-slice s takes the
+  long split_y;                   // k-tiles [s * nk / ksplit, (s + 1) * nk / ksplit) and writes its partial sums to y + s * split_y
   int half_mode;                  // 1: fp16 operands on v_mfma_f32_32x32x16_f16 (glass_conv2d_nhwc_f16)
   int xh, yh, rh;                 // half_mode only (glass_conv2d_nhwc_h16): x / y / residual are fp16 tensors in HBM
 };
@@ -58,7 +60,15 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int NSTAGE, int MINW, int BK, int MODE, bool HALF>
-__global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
+__global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams pin) {
+  ConvParams p = pin;
+  int kt0 = 0, kt1 = pin.nk;       // this workgroup's k-tiles
+  if (pin.ksplit > 1) {           // split-K: blockIdx.y's share of the k-tiles; partial sums go to slice blockIdx.y of the workspace
+    const int per = pin.nk / pin.ksplit;
+    kt0 = (int)blockIdx.y * per;
+    kt1 = kt0 + per;
+    p.y += (long)blockIdx.y * pin.split_y;
+  }
   constexpr bool FAST = MODE == 1, BUF = MODE != 0;
   constexpr int LDS_LD = HALF ? BK + 8 : BK + 4;      // elements (halfs / floats) per staged row incl. the conflict pad
   constexpr int KCH = BK / 4;            // 16-byte chunks per staged row
@@ -134,6 +144,12 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   unsigned b_voff[B_LOADS];
   __amdgpu_buffer_rsrc_t xr, wr;
   int f_dh = 0, f_dw = 0, f_c0 = 0;          // uniform: tap row / column, first channel of the current k-tile
+  if (FAST && kt0 != 0) {                    // a split-K slice starts in the middle of the (tap, channel) walk
+    const int tap = (kt0 * BK) / p.Cin;
+    f_c0 = kt0 * BK - tap * p.Cin;
+    f_dh = tap / p.KW;
+    f_dw = tap - f_dh * p.KW;
+  }
   if constexpr (BUF) {
     xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
@@ -272,15 +288,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
   const _Float16* a_frag0h = hmem + (wm * TM * 32 + frag_row) * LDS_LD + (lane >> 5) * 8;
   const _Float16* b_frag0h = hmem + BM * LDS_LD + (wn * TN * 32 + frag_row) * LDS_LD + (lane >> 5) * 8;
 
-  load_tile(0);
+  load_tile(kt0);
   store_tile(0);
   __syncthreads();
-  for (int kt = 0; kt < p.nk; ++kt) {
-    const bool more = kt + 1 < p.nk;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
     // buffer-load modes: unconditional (after the last k-tile the bounds-checked loads just return zeros / unused data),
     // so the whole k-tile is one scheduling region and the loads can be metered out between the MFMAs below
     if (BUF || more) load_tile(kt + 1);
-    const int cur = NSTAGE == 2 ? (kt & 1) : 0;
+    const int cur = NSTAGE == 2 ? ((kt - kt0) & 1) : 0;
     if constexpr (HALF) {
       const _Float16* a_frag = a_frag0h + cur * STAGE;
       const _Float16* b_frag = b_frag0h + cur * STAGE;
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(ConvParams p) {
     }
     if (NSTAGE == 2) {
       // stage (kt+1)&1 was last read in iteration kt-1, which every wave left through the barrier below
-      if (more) store_tile((kt + 1) & 1);
+      if (more) store_tile((kt + 1 - kt0) & 1);
       __syncthreads();
     } else {
       __syncthreads();
@@ -491,12 +507,13 @@ static int launch_conv_cfg(ConvParams& p, hipStream_t stream) {
     return GLASS_EINVAL;
   }
   p.nk = cdiv(p.Ktot, BK);
+  const dim3 grid((unsigned)nblk, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
   if (p.x_bytes != 0 && p.Cin % BK == 0)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 1, HALF>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 1, HALF>), grid, dim3(256), 0, stream, p);
   else if (p.x_bytes != 0)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 2, HALF>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 2, HALF>), grid, dim3(256), 0, stream, p);
   else if constexpr (!HALF)
-    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 0, false>), dim3((unsigned)nblk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, NSTAGE, MINW, BK, 0, false>), grid, dim3(256), 0, stream, p);
   else {
     glass_set_error("glass_conv2d_nhwc_f16: tensors of 2 GiB and more are not supported in the fp16 mode");
     return GLASS_EINVAL;
@@ -567,6 +584,7 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   GLASS_CHECK_ARG(M < 0x7fffffffL, "glass_conv2d_nhwc: too many output pixels");
   p.M = (int)M;
   p.Ktot = d->KH * d->KW * d->Cin;
+  p.ksplit = 1; p.split_y = 0;
   {
     // the buffer-load paths need 31-bit byte offsets (MODE 1 additionally Cin % 32 == 0, checked at launch)
     // (offsets are computed as fp32 byte offsets and halved for fp16 tensors: the fp32-sized span must fit 31 bits)
@@ -616,4 +634,111 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
   if (p.M <= 64 || tiles128 < 640) return launch_conv_impl<1, 4, 2, 1, 1, 4, 32>(p, s);   // 64 x 128
   return launch_conv_impl<2, 2, 2, 2, 1, 3, 32>(p, s);                      // 128 x 128, 3 blocks/CU
   // (measured on MI355X: BK=64 with 2 blocks/CU and a 2-stage LDS pipeline are both within 2% of this)
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- split-K
+// y = act(conv(x, w) + bias [+ residual]) for FEW output pixels and a LONG K - the layers that leave most of the chip idle
+// when one image is in flight (reference predictor: glass/inference/glass_runner.py:93-96 is one image per call): the box
+// head's fc1 on 100 proposals (M = 100, K = 12544: 64 workgroups x 392 sequential k-tiles, 0.38 ms at 13 TFLOP/s), res4 /
+// res5 3x3 layers on 64 x 64 / 32 x 32 maps (K = 2304 / 4608), the 11-row box predictors (ONE workgroup).  The same
+// implicit-GEMM kernel runs `splits` k-slices as grid.y (slice s = k-tiles [s nk / splits, (s+1) nk / splits) of the
+// (tap, channel) walk), slice s writes raw partial sums to workspace[s][M][Cout], and a second kernel adds them IN SLICE
+// ORDER (deterministic), then bias, ReLU, residual as the single-slice epilogue does, and writes y with its strides.
+namespace {
+struct SplitReduce {
+  const float* ws; const float* bias; const float* res; float* y;
+  long M; int Cout, splits, ldy, ycoff, ycs, ldr, relu, res_mode;
+};
+template <int V>   // V = 4: four channels per thread (unit channel stride, aligned), 1: one
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduce q) {
+  const long per = q.M * q.Cout;
+  const int cv = q.Cout / V;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per / V; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / cv;
+    const int c = (int)(i - m * cv) * V;
+    float a[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = 0.f;
+    for (int s = 0; s < q.splits; ++s) {
+      if constexpr (V == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(q.ws + (long)s * per + m * q.Cout + c);
+        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+      } else {
+        a[0] += q.ws[(long)s * per + m * q.Cout + c];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float v = a[e] + (q.bias ? q.bias[c + e] : 0.f);
+      if (q.relu == 2) v = fmaxf(v, 0.f);
+      if (q.res_mode == 1) v += q.res[m * q.ldr + c + e];
+      if (q.relu == 1) v = fmaxf(v, 0.f);
+      a[e] = v;
+    }
+    if constexpr (V == 4) *reinterpret_cast<float4*>(q.y + m * q.ldy + q.ycoff + c) = make_float4(a[0], a[1], a[2], a[3]);
+    else q.y[m * q.ldy + q.ycoff + (long)c * q.ycs] = a[0];
+  }
+}
+}  // namespace
+
+extern "C" int64_t glass_conv2d_splitk_workspace_bytes(const glass_conv_desc* d, int splits) {
+  if (!d) return 0;
+  return (int64_t)splits * d->N * d->Ho * d->Wo * d->Cout * (int64_t)sizeof(float);
+}
+
+// every k-slice a whole number of 32-channel k-tiles (the uniform-tap load path), residual not upsampled, operands < 2 GiB
+extern "C" int glass_conv2d_splitk_supported(const glass_conv_desc* d, int splits) {
+  if (!d) return 0;
+  const long M = (long)d->N * d->Ho * d->Wo, K = (long)d->KH * d->KW * d->Cin;
+  return M > 0 && d->Cout > 0 && d->Cin % 32 == 0 && splits >= 2 && splits <= 32 && (K / 32) % splits == 0 && d->ldx % 4 == 0 &&
+         d->ldx >= d->Cin && (d->res_mode == 0 || d->res_mode == 1) &&
+         (long)d->N * d->H * d->W * d->ldx * 4 < 0x7fffff00L && (long)d->Cout * K * 4 < 0x7fffff00L && M * d->Cout * 4 < 0x7fffff00L;
+}
+
+extern "C" int glass_conv2d_nhwc_splitk(const glass_conv_desc* d, const float* x, const float* w, const float* bias,
+                                        const float* residual, float* y, int splits, void* workspace, int64_t workspace_bytes,
+                                        glass_stream_t stream) {
+  GLASS_CHECK_ARG(d && x && w && y && workspace, "glass_conv2d_nhwc_splitk: null pointer");
+  GLASS_CHECK_ARG(glass_conv2d_splitk_supported(d, splits),
+                  "glass_conv2d_nhwc_splitk: needs Cin %% 32 == 0, (KH KW Cin / 32) %% splits == 0, 2 <= splits <= 32, res_mode 0/1 and "
+                  "operands < 2 GiB (got Cin=%d k=%dx%d splits=%d res_mode=%d)", d->Cin, d->KH, d->KW, splits, d->res_mode);
+  GLASS_CHECK_ARG(d->Ho == (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1 && d->Wo == (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1,
+                  "glass_conv2d_nhwc_splitk: Ho/Wo (%d,%d) inconsistent with input/kernel/stride/pad", d->Ho, d->Wo);
+  GLASS_CHECK_ARG(d->y_cstride >= 1 && d->y_coff >= 0 && (long)d->y_coff + (long)(d->Cout - 1) * d->y_cstride < (long)d->ldy,
+                  "glass_conv2d_nhwc_splitk: output channel window exceeds ldy=%d", d->ldy);
+  GLASS_CHECK_ARG(d->res_mode == 0 || (residual != nullptr && d->ldr >= d->Cout), "glass_conv2d_nhwc_splitk: bad residual");
+  GLASS_CHECK_ARG(workspace_bytes >= glass_conv2d_splitk_workspace_bytes(d, splits), "glass_conv2d_nhwc_splitk: workspace too small");
+  GLASS_CHECK_ARG((((uintptr_t)x | (uintptr_t)w | (uintptr_t)workspace) & 15) == 0, "glass_conv2d_nhwc_splitk: x / w / workspace must be 16-byte aligned");
+  GLASS_CHECK_ARG(d->relu >= 0 && d->relu <= 2, "glass_conv2d_nhwc_splitk: relu must be 0, 1 or 2");
+  const long M = (long)d->N * d->Ho * d->Wo;
+  ConvParams p;
+  p.half_mode = 0; p.xh = p.yh = p.rh = 0;
+  p.x = x; p.w = w; p.bias = nullptr; p.res = nullptr; p.y = static_cast<float*>(workspace);
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.KH = d->KH; p.KW = d->KW;
+  p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.ldx = d->ldx; p.ldy = d->Cout; p.ycoff = 0; p.ycs = 1; p.relu = 0; p.res_mode = 0; p.ldr = 0;
+  p.M = (int)M; p.Ktot = d->KH * d->KW * d->Cin; p.ksplit = splits; p.split_y = M * d->Cout;
+  p.x_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldx * 4);
+  p.w_bytes = (unsigned)((long)d->Cout * p.Ktot * 4);
+  p.magic_cin = (unsigned)(0x100000000ULL / (unsigned long long)d->Cin);
+  p.magic_kw = (unsigned)(0x100000000ULL / (unsigned long long)d->KW);
+  p.vec_epi = d->Cout % 4 == 0 ? 1 : 0;
+  p.y_bytes = (unsigned)(M * d->Cout * 4);     // one slice: the kernel's y is already the slice's base
+  p.r_bytes = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = d->Cout <= 32 ? launch_conv_impl<4, 1, 1, 1, 1, 4, 32>(p, s)          // 128 x 32 tiles (box predictors)
+                               : launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);         // 64 x 64 tiles, 8 workgroups per CU
+  if (rc != GLASS_OK) return rc;
+  SplitReduce q;
+  q.ws = static_cast<const float*>(workspace); q.bias = bias; q.res = d->res_mode ? residual : nullptr; q.y = y;
+  q.M = M; q.Cout = d->Cout; q.splits = splits; q.ldy = d->ldy; q.ycoff = d->y_coff; q.ycs = d->y_cstride; q.ldr = d->ldr;
+  q.relu = d->relu; q.res_mode = d->res_mode;
+  const bool vec = d->Cout % 4 == 0 && d->y_cstride == 1 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && ((uintptr_t)y & 15) == 0;
+  const long n = M * d->Cout / (vec ? 4 : 1);
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, s, q);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, q);
+  GLASS_CHECK_LAUNCH("glass_conv2d_nhwc_splitk");
+  return GLASS_OK;
 }

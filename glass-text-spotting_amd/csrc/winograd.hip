@@ -598,8 +598,28 @@ extern "C" int glass_winograd_pack_weights(const float* w, int Cout, int Cin, fl
   return GLASS_OK;
 }
 
+static int wino_launch(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias, const float* residual,
+                       float* y, glass_stream_t stream, bool body_only);
+
 extern "C" int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
                                            const float* bias, const float* residual, float* y, glass_stream_t stream) {
+  return wino_launch(d, x, u_packed, bias, residual, y, stream, false);
+}
+
+// Only the FULL 2-column tile columns: output columns [0, 2 * (W / 2)) of every row (the F(2x2) sibling of
+// glass_conv3x3_winograd43_body_nhwc).  A map of odd width - the local extractor's 16 x 33 maps, reference
+// local_feature_extraction.py:123 - otherwise pays a 17th tile column for one pixel column, and with one image in flight
+// (32 RoIs: 17 x 8 x 32 = 4352 tiles = 272 workgroups of 32 tiles x 128 channels) that extra column is what turns ONE round
+// on the 256 CUs into two: 143 -> 75 us per layer + the strip.  The caller computes the last column with
+// glass_conv2d_nhwc on the 2-column strip (ops/native.py _last_column_strip).
+extern "C" int glass_conv3x3_winograd_body_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
+                                                const float* bias, const float* residual, float* y, glass_stream_t stream) {
+  GLASS_CHECK_ARG(d && d->W >= 2, "glass_conv3x3_winograd_body_nhwc: needs W >= 2");
+  return wino_launch(d, x, u_packed, bias, residual, y, stream, true);
+}
+
+static int wino_launch(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias, const float* residual,
+                       float* y, glass_stream_t stream, bool body_only) {
   GLASS_CHECK_ARG(d && x && u_packed && y, "glass_conv3x3_winograd_nhwc: null pointer");
   GLASS_CHECK_ARG(glass_winograd_supported(d),
                   "glass_conv3x3_winograd_nhwc: needs 3x3/stride 1/pad 1, Cin%%16==0, Cout%%64==0, unit channel stride, "
@@ -613,7 +633,7 @@ extern "C" int glass_conv3x3_winograd_nhwc(const glass_conv_desc* d, const float
   WinoParams p;
   p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y; p.dbg = nullptr;
   p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
-  p.TH = (d->H + 1) / 2; p.TW = (d->W + 1) / 2;
+  p.TH = (d->H + 1) / 2; p.TW = body_only ? d->W / 2 : (d->W + 1) / 2;      // (input / output bounds still use the true W)
   const long nt = (long)d->N * p.TH * p.TW;
   GLASS_CHECK_ARG(nt < 0x7fffffffL, "glass_conv3x3_winograd_nhwc: too many tiles");
   p.ntiles = (int)nt;

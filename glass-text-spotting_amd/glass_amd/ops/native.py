@@ -115,13 +115,18 @@ class Routing:
                   interleaves - "1x1" (default: shortest chain, 3 % off the one-step-at-a-time latency), "2x1", "2x2",
                   "persistent" = the library's default - or "steps" (GLASS_RNN=steps: one launch per time step,
                   csrc/recognition.hip); outputs are bit-identical
+      splitk      implicit-GEMM launches with few output pixels and a long K (one image per step: the box head's fc layers on
+                  100 rows, res4 / res5 3x3, the 11-row predictors) as a split-K launch + ordered reduction (GLASS_SPLITK=0)
+      small_grid  3x3 layers whose F(4x4) grid does not fill the chip pick their Winograd form by rounds x workgroup time,
+                  incl. the F(2x2) body + strip form for odd widths (GLASS_SMALL_GRID=0: the batch-8 rules only)
       pooled_fusion  P2P3Fusion's two 1x1 convolutions AFTER the recognizer pooler (on the pooled bins) instead of on the whole
                   p2 / p3 maps - RoIAlign and the fusion are both linear (GLASS_POOLED_FUSION=0: whole-map fusion, then pool)"""
-    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion", "rnn")
+    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion", "rnn", "splitk", "small_grid")
 
     def __init__(self, precision: Optional[str] = None, winograd: Optional[bool] = None, f43: Optional[bool] = None, pw=None,
                  h16: Optional[bool] = None, local_stem: Optional[bool] = None, stem: Optional[bool] = None,
-                 ragged: Optional[bool] = None, pooled_fusion: Optional[bool] = None, rnn=None):
+                 ragged: Optional[bool] = None, pooled_fusion: Optional[bool] = None, rnn=None,
+                 splitk: Optional[bool] = None, small_grid: Optional[bool] = None):
         e = os.environ.get
         self.precision = precision or e("GLASS_CONV_PRECISION", "fp32")
         if self.precision not in _PRECISIONS:
@@ -135,6 +140,8 @@ class Routing:
         self.ragged = (e("GLASS_W43_RAGGED", "1") != "0") if ragged is None else bool(ragged)
         self.pooled_fusion = (e("GLASS_POOLED_FUSION", "1") != "0") if pooled_fusion is None else bool(pooled_fusion)
         self.rnn = _parse_rnn(e("GLASS_RNN", "1x1")) if rnn is None else _parse_rnn(rnn)
+        self.splitk = (e("GLASS_SPLITK", "1") != "0") if splitk is None else bool(splitk)
+        self.small_grid = (e("GLASS_SMALL_GRID", "1") != "0") if small_grid is None else bool(small_grid)
 
     def replace(self, **kw) -> "Routing":
         r = Routing.__new__(Routing)
@@ -268,6 +275,35 @@ def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int, body: bool = False) ->
     wide = Cout % 128 == 0 and Cin % 32 == 0
     blocks = ((N * t4 + 15) // 16) * (Cout // 128) if wide else ((N * t4 + 31) // 32) * (Cout // 64)
     return waste <= 1.25 and blocks >= 192
+
+
+NUM_CUS = 256
+
+
+def _small_grid_3x3(N: int, H: int, W: int, Cout: int, Cin: int, can_body: bool, f43_ok: bool):
+    """3x3 / stride-1 layers whose F(4x4) grid does NOT fill the chip (`_use_f43` said no) - every trunk layer once ONE image
+    is in flight (the reference predictor's batch, glass_runner.py:93-96): pick the Winograd form by ROUNDS x the time one
+    workgroup takes.  All of these kernels run one workgroup per CU, so a launch costs ceil(workgroups / 256) rounds of a
+    workgroup's duration, which is linear in Cin (measured on MI355X, profiles/r05_conv_table_b1_before.txt and the batch-8
+    tables, scripts/exp_small_grid.py: F(4x4) wide 10 + 0.34 Cin us, narrow 9 + 0.56 Cin, F(2x2) 128-channel 9 + 0.30 Cin, F(2x2)
+    64-channel 3 Cin).
+    Returns (kind, body): kind "f43" | "f22", body True = full tile columns + the last-column strip (odd widths; ~20 us)."""
+    def rounds(blocks):
+        return -(-blocks // NUM_CUS)
+    cands = []
+    wide43 = Cout % 128 == 0 and Cin % 32 == 0
+    wide22 = Cout % 128 == 0 and Cin % 32 == 0
+    for body in ((False, True) if can_body else (False,)):
+        strip = 20.0 if body else 0.0
+        if f43_ok and (not body or W % 4 == 1):
+            t4 = N * ((H + 3) // 4) * (W // 4 if body else (W + 3) // 4)
+            blocks = -(-t4 // 16) * (Cout // 128) if wide43 else -(-t4 // 32) * (Cout // 64)
+            cands.append((rounds(blocks) * ((10 + 0.34 * Cin) if wide43 else (9 + 0.56 * Cin)) + strip, "f43", body))
+        t2 = N * ((H + 1) // 2) * (W // 2 if body else (W + 1) // 2)
+        blocks = -(-t2 // 32) * (Cout // 128) if wide22 else -(-t2 // 64) * (Cout // 64)
+        cands.append((rounds(blocks) * ((9 + 0.30 * Cin) if wide22 else 3.0 * Cin) + strip, "f22", body))
+    _, kind, body = min(cands)
+    return kind, body
 
 
 class ConvWeight:
@@ -405,7 +441,7 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     forms built at load) or a plain device tensor (packed per launch where the chosen kernel needs it).
     3x3/stride 1/pad 1 layers that glass_winograd_supported() accepts go through the Winograd kernel
     (winograd=None: follow the routing; True/False force F(2x2,3x3) on / off for this call, "f43" forces the F(4x4,3x3)
-    kernel).  Which kernel runs is decided by `routing` (default: the Routing stamped on `w` at model load, else the
+    kernel, "f22r" F(2x2,3x3) on the full tile columns of an odd-width map + the last-column strip).  Which kernel runs is decided by `routing` (default: the Routing stamped on `w` at model load, else the
     raw-tensor default) with `precision` overriding its precision for this call - nothing process-global is read for a
     model's layers."""
     wt = w.raw if isinstance(w, ConvWeight) else _f32c(w, "w")
@@ -492,15 +528,30 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
         use_wino = ((N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (Cout // 64) >= 96
     # (a model's layer takes the split only if its load prepared the strip weights - fold_conv(..., ragged=True) - so that no
     #  launch of the model path ever packs; raw tensors (tests, scripts) get them packed for the launch)
-    ragged = (rt.ragged and KH == 3 and KW == 3 and W % 4 == 1 and W >= 5 and (2 * Cin) % 32 == 0 and out_cstride == 1 and
-              ldx == Cin and res_mode in (0, 1) and x.numel() > 0 and (not isinstance(w, ConvWeight) or "col1" in w.packs))
+    # odd widths (the local extractor's 16 x 33 maps): full tile columns on a Winograd kernel + the last pixel column as a strip
+    # convolution.  A model's layer takes the split only if its load prepared the strip weights - fold_conv(..., ragged=True) -
+    # so that no launch of the model path ever packs; raw tensors (tests, scripts) get them packed for the launch.
+    strip_ok = (rt.ragged and KH == 3 and KW == 3 and W % 2 == 1 and W >= 5 and (2 * Cin) % 32 == 0 and out_cstride == 1 and
+                ldx == Cin and res_mode in (0, 1) and x.numel() > 0 and (not isinstance(w, ConvWeight) or "col1" in w.packs))
+    ragged = strip_ok and W % 4 == 1
     f43 = winograd == "f43" or (winograd is None and rt.f43 and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin, ragged))
+    f22_body = False
+    if winograd == "f22r":                          # forced: F(2x2) on the full tile columns + the last-column strip (tests)
+        if not strip_ok:
+            raise GlassLibraryError("winograd='f22r' needs an odd width >= 5, dense input, unit channel stride and res_mode 0/1")
+        f22_body = True
+    if (winograd is None and use_wino and not f43 and KH == 3 and KW == 3 and rt.small_grid and
+            lib().glass_winograd_supported(ctypes.byref(d))):
+        # the F(4x4) grid does not fill the chip (one image in flight): rounds x workgroup time decides
+        kind, body = _small_grid_3x3(N, H, W, Cout, Cin, strip_ok,
+                                     rt.f43 and bool(lib().glass_winograd43_supported(ctypes.byref(d))))
+        f43, ragged, f22_body = kind == "f43", kind == "f43" and body, kind == "f22" and body
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
         if ragged:
-            # width 4 k + 1 (the local extractor's 16 x 33 maps): the F(4x4) kernel on the k full tile columns - 32 instead of
-            # 36 tiles per 16 x 33 map, and e.g. 1024 instead of 1152 workgroups = 4 instead of 4.5 rounds on 256 CUs - and
-            # the last pixel column as a KH = 3, KW = 1 convolution over the last two input columns seen as 2*Cin channels
-            # (x, y and the residual re-viewed as [N,H,1,W*ld] rows with a channel offset; no copy)
+            # width 4 k + 1: the F(4x4) kernel on the k full tile columns - 32 instead of 36 tiles per 16 x 33 map, and e.g.
+            # 1024 instead of 1152 workgroups = 4 instead of 4.5 rounds on 256 CUs - and the last pixel column as a KH = 3,
+            # KW = 1 convolution over the last two input columns seen as 2*Cin channels (x, y and the residual re-viewed as
+            # [N,H,1,W*ld] rows with a channel offset; no copy)
             launch("glass_conv3x3_winograd43_body_nhwc", "winograd43", x, _packed(w, wt, True))
             _last_column_strip(x, _packed(w, wt, "col1"), bias, residual, out, d, out_coff)
             _TLS.last_path = "winograd43r"          # (bench / profiling: F(4x4) body + last-column strip)
@@ -509,10 +560,28 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     if winograd == "f43":
         raise GlassLibraryError("winograd='f43' but glass_winograd43_supported() rejects this layer")
     if use_wino and KH == 3 and KW == 3 and lib().glass_winograd_supported(ctypes.byref(d)):
-        return launch("glass_conv3x3_winograd_nhwc",
-                      "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd", x, _packed(w, wt, False))
+        path = "winograd128" if lib().glass_winograd_block_channels(Cout, Cin) == 128 else "winograd"
+        if f22_body:
+            launch("glass_conv3x3_winograd_body_nhwc", path, x, _packed(w, wt, False))
+            _last_column_strip(x, _packed(w, wt, "col1"), bias, residual, out, d, out_coff)
+            _TLS.last_path = path + "r"             # (F(2x2) body + last-column strip)
+            return out
+        return launch("glass_conv3x3_winograd_nhwc", path, x, _packed(w, wt, False))
     if winograd:
         raise GlassLibraryError("winograd=True but glass_winograd_supported() rejects this layer")
+    splits = _splitk_slices(rt, N * Ho * Wo, KH * KW * Cin, Cin, Cout) if (res_mode in (0, 1) or residual is None) else 0
+    if splits > 1 and out.dtype == torch.float32 and x.dtype == torch.float32 and lib().glass_conv2d_splitk_supported(ctypes.byref(d), splits):
+        # few output pixels and a long K (one image in flight: box head fc layers, res4 / res5 3x3, the 11-row predictors):
+        # the k-tiles as `splits` independent slices of workgroups, partial sums through a workspace, ordered reduction
+        nbytes = int(lib().glass_conv2d_splitk_workspace_bytes(ctypes.byref(d), splits))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        _TLS.last_path = "direct"
+        check(lib().glass_conv2d_nhwc_splitk(ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(wt, "w")),
+                                             c_void_p(_dev(bias, "bias") if bias is not None else None),
+                                             c_void_p(_dev(residual, "residual") if residual is not None else None),
+                                             c_void_p(_dev(out, "out")), splits, c_void_p(_dev(ws)), ctypes.c_int64(nbytes),
+                                             c_void_p(stream_handle())), "glass_conv2d_nhwc_splitk")
+        return out
     return launch("glass_conv2d_nhwc", "direct", x, wt)
 
 
@@ -532,12 +601,40 @@ def _last_column_strip(x: torch.Tensor, wcol: torch.Tensor, bias, residual, out:
                                   c_void_p(stream_handle())), "glass_conv2d_nhwc(last column)")
 
 
+def _splitk_slices(rt: Routing, M: int, Ktot: int, Cin: int, Cout: int) -> int:
+    """k-slices for an implicit-GEMM launch that is latency-bound behind a long k-loop (0: a single slice).  Cost model from
+    scripts/exp_small_grid.py on MI355X (64 x 64 tiles, 8 workgroups resident per CU; 128 x 32 for Cout <= 32): a workgroup
+    alone on its CU takes ~0.75 us per 32-deep k-tile (load -> LDS -> barrier latency), w > 1 workgroups per CU take
+    ~0.3 + 0.45 w us per k-tile of all of them (the CU retires one k-tile per ~0.45 us), so
+    T(s) = nk / s * per_ktile(tiles * s / 256)  +  the partial sums once out and once back at ~4 TB/s  +  ~5 us for the
+    reduction launch.  The split is taken when it saves >= 15 %.
+    (box head fc1, 12544 -> 2048: 100 rows 298 -> 64 us with 8 slices, 800 rows 424 -> 348; res5 3x3 at 32 x 32: 112 -> 47.)"""
+    if not rt.splitk or rt.precision != "fp32" or Cin % 32 != 0 or M <= 0:
+        return 0
+    nk = Ktot // 32
+    if nk < 16:
+        return 0
+    tiles = -(-M // 128) if Cout <= 32 else -(-M // 64) * -(-Cout // 64)
+
+    def t(s):
+        wpc = max(1.0, tiles * s / NUM_CUS)
+        extra = 0.0 if s == 1 else 2.0 * s * M * Cout * 4 / 4e6 + 5.0 + 0.3 * s
+        return nk / s * (0.75 if wpc <= 1.0 else 0.3 + 0.45 * wpc) + extra
+    best, tbest = 0, 0.85 * t(1)
+    for s in (2, 3, 4, 6, 7, 8, 9, 12, 14, 16, 18, 24, 28, 32):
+        if nk % s == 0 and nk // s >= 4 and t(s) < tbest:
+            best, tbest = s, t(s)
+    return best
+
+
 def linear(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, relu: int = 0,
-           out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, precision: Optional[str] = None) -> torch.Tensor:
-    """x [M,K] @ w[Nout,K]^T + bias on the same MFMA kernel (H = W = KH = KW = 1)."""
+           out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, precision: Optional[str] = None,
+           routing: Optional[Routing] = None) -> torch.Tensor:
+    """x [M,K] @ w[Nout,K]^T + bias on the same MFMA kernel (H = W = KH = KW = 1); few-row / long-K fp32 layers go through
+    glass_conv2d_nhwc_splitk (conv2d_nhwc routes them)."""
     M, K = x.shape
     y = conv2d_nhwc(x.view(M, 1, 1, K), w if isinstance(w, ConvWeight) else w.view(w.shape[0], 1, 1, K), bias, relu=relu,
-                    out=None if out is None else out.view(M, 1, 1, -1), out_dtype=out_dtype, precision=precision)
+                    out=None if out is None else out.view(M, 1, 1, -1), out_dtype=out_dtype, precision=precision, routing=routing)
     return y.view(M, -1)
 
 

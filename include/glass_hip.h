@@ -141,6 +141,11 @@ int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, cons
  * channels = (kw, cin), see glass_amd/ops/native.py).  Same descriptor (the TRUE H, W), epilogue and errors.          */
 int glass_conv3x3_winograd43_body_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                        const float* residual, float* y, glass_stream_t stream);
+/* ... and the F(2x2,3x3) kernel restricted to its full tile columns: output columns [0, 2 * (W / 2)) (W >= 2), packed
+ * weights of glass_winograd_pack_weights.  With one image in flight the 16 x 33 maps of 32 RoIs are 272 workgroups on the full
+ * grid (two rounds on 256 CUs) and exactly 256 on the body grid; the last column is the same strip convolution.           */
+int glass_conv3x3_winograd_body_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
+                                     const float* residual, float* y, glass_stream_t stream);
 
 /* 1x1 convolution as a weight-streaming GEMM (csrc/pointwise.hip): the bottleneck / lateral / shortcut 1x1 layers with
  * Cin % 32 == 0 and Cout % 128 == 0, any square stride, pad 0.  Same descriptor, epilogue semantics (bias, ReLU before /
@@ -168,6 +173,18 @@ int glass_local_stem_fused(const float* x, const float* w1, const float* b1, con
  * fp16 - the results of glass_conv2d_nhwc_h16 x 2 + glass_maxpool2d_nhwc_h16 up to fp32 summation order.            */
 int glass_local_stem_fused_h16(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, void* y,
                                int R, int H, int W, glass_stream_t stream);
+
+/* Split-K form of glass_conv2d_nhwc for FEW output pixels and a LONG K - what one image per call (the reference predictor,
+ * glass/inference/glass_runner.py:93-96) leaves of the box head (reference recognizers_hybrid_head.py:320-322 -> d2
+ * FastRCNNConvFCHead [d2-recall]: 100 x 12544 -> 2048), of the res4 / res5 3x3 layers and of the 11-row box predictors:
+ * same descriptor, operands, epilogue (bias, relu 0/1/2, res_mode 0/1, strided output) and results up to fp32 summation
+ * order; the k-tiles are cut into `splits` slices that run as independent workgroups of the implicit-GEMM kernel (partial
+ * sums in `workspace`, >= glass_conv2d_splitk_workspace_bytes), added in slice order by a second kernel - deterministic.
+ * glass_conv2d_splitk_supported: Cin % 32 == 0, (KH KW Cin / 32) % splits == 0, 2 <= splits <= 32, res_mode 0/1, fp32.   */
+int glass_conv2d_splitk_supported(const glass_conv_desc* d, int splits);
+int64_t glass_conv2d_splitk_workspace_bytes(const glass_conv_desc* d, int splits);
+int glass_conv2d_nhwc_splitk(const glass_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual,
+                             float* y, int splits, void* workspace, int64_t workspace_bytes, glass_stream_t stream);
 
 /* Fused ResNet stem (detectron2 BasicStem, [d2-recall], as restated in oracle/glass_cpu.py resnet50_fpn):
  * conv 7x7 stride 2 pad 3 (3 -> 64, BatchNorm folded into w / bias) + ReLU + max_pool2d(3, 2, 1) in ONE kernel

@@ -63,9 +63,12 @@ def test_runner_matches_oracle_and_batch_equals_single():
     batch = runner.run_batch(imgs)
     for a, b in zip(single, batch):
         assert len(a) == len(b)
-        np.testing.assert_allclose(a.pred_boxes.tensor.cpu().numpy(), b.pred_boxes.tensor.cpu().numpy(), atol=1e-4)
+        # (up to fp32 summation order: which kernel a layer takes depends on how many output pixels the call has - a one-image
+        #  call cuts its long-K layers into k-slices, a two-image call may not - so "the same" means the path's 1e-3 bar on
+        #  boxes, measured 2.2e-4 px / 8.5e-6 relative, and 1e-4 on probabilities; kept indices and counts are identical)
+        np.testing.assert_allclose(a.pred_boxes.tensor.cpu().numpy(), b.pred_boxes.tensor.cpu().numpy(), atol=1e-3)
         if len(a):
-            np.testing.assert_allclose(a.pred_text_prob.cpu().numpy(), b.pred_text_prob.cpu().numpy(), atol=1e-5)
+            np.testing.assert_allclose(a.pred_text_prob.cpu().numpy(), b.pred_text_prob.cpu().numpy(), atol=1e-4)
     for im, got in list(zip(imgs, single))[:2]:
         r = runner.get_inference_scale_ratio(im.shape)
         t = torch.from_numpy(im).permute(2, 0, 1).float()
@@ -305,7 +308,8 @@ def test_runner_batch_with_device_postprocess_equals_single_calls():
     for a, b, im in zip(single, batch, imgs):
         assert a.image_size == tuple(im.shape[:2]) == b.image_size
         assert len(a) == len(b)
-        np.testing.assert_allclose(a.pred_boxes.tensor.cpu().numpy(), b.pred_boxes.tensor.cpu().numpy(), atol=1e-4)
+        # (1e-3: a one-image call and a batch may take different kernels for the same layer - fp32 summation order)
+        np.testing.assert_allclose(a.pred_boxes.tensor.cpu().numpy(), b.pred_boxes.tensor.cpu().numpy(), atol=1e-3)
         assert a.pred_texts == b.pred_texts
         assert a.pred_polygons.shape == (len(a), 4, 2)
 

@@ -183,6 +183,111 @@ def test_roi_align_up2_equals_pooling_the_materialised_upsampled_map():
         K.roi_align_rotated([x.half()], [0.25], boxes, bidx, (8, 32), 0, up2=True)
 
 
+@pytest.mark.parametrize("R,H,W,Cin,Cout,relu,use_res,forced", [
+    (32, 16, 33, 256, 256, 1, True, True),        # one image's 32 RoIs: 272 workgroups on the full grid, 256 on the body grid
+    (32, 16, 33, 128, 256, 1, False, True),
+    (5, 10, 7, 64, 64, 2, True, True),            # width 4 k + 3: only the F(2x2) split applies; 64-channel kernel
+    (3, 6, 9, 32, 128, 0, False, True),
+])
+def test_winograd22_odd_width_split_vs_torch(R, H, W, Cin, Cout, relu, use_res, forced):
+    """Odd-width maps on the F(2x2,3x3) kernels: full tile columns (glass_conv3x3_winograd_body_nhwc) + the last pixel column as
+    the strip convolution - the form the small-grid routing picks for the local extractor's 16 x 33 maps when ONE image is in
+    flight (reference local_feature_extraction.py:103-132 on 32 RoIs) - against torch CPU fp64, every column."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    x = _rand((R, Cin, H, W), 31)
+    w = _rand((Cout, Cin, 3, 3), 32, (2.0 / (Cin * 9)) ** 0.5)
+    b = _rand((Cout,), 33, 0.1)
+    res = _rand((R, Cout, H, W), 34) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu == 2:
+        ref = F.relu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    if relu == 1:
+        ref = F.relu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    cw = K.prepare_conv_weights(w.permute(0, 2, 3, 1).contiguous().to(dev), ragged=True)
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
+    n0 = K.packs_on_the_fly()
+    y = K.conv2d_nhwc(xd, cw, b.to(dev), padding=1, relu=relu, residual=rd, res_mode=1 if rd is not None else 0,
+                      winograd="f22r" if forced else None)
+    assert K.last_conv_path() in ("winograd128r", "winogradr"), K.last_conv_path()
+    assert forced or K.packs_on_the_fly() == n0
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    scale = float(ref.abs().max())
+    e_body = float((got[..., :W - 1] - ref[..., :W - 1]).abs().max()) / scale
+    e_last = float((got[..., W - 1] - ref[..., W - 1]).abs().max()) / scale
+    print(f"F(2x2,3x3) odd-width split [{R},{H},{W},{Cin}]->{Cout}: max err / range = {e_body:.2e} (tile columns), {e_last:.2e} (last column)")
+    assert e_body <= 5e-6 and e_last <= 5e-6
+
+
+@pytest.mark.parametrize("M,Kdim,Nout,relu", [(800, 12544, 2048, 1), (100, 12544, 2048, 1), (100, 2048, 11, 0), (37, 4096, 256, 0), (300, 8192, 320, 2)])
+def test_linear_splitk_matches_single_slice_and_torch(M, Kdim, Nout, relu):
+    """glass_conv2d_nhwc_splitk on linear layers (box head fc1 / fc2 / predictors with one image in flight, reference
+    recognizers_hybrid_head.py:320-322: few rows, K = 256 x 7 x 7): k-slices as independent workgroups + an ordered reduction
+    with bias / ReLU, against the single-slice kernel and torch CPU fp64; the result is deterministic (two runs bit-identical)."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    x = _rand((M, Kdim), 41)
+    w = _rand((Nout, Kdim), 42, (2.0 / Kdim) ** 0.5)
+    b = _rand((Nout,), 43, 0.1)
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = F.relu(ref)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    assert K._splitk_slices(K.default_routing(), M, Kdim, Kdim, Nout) > 1
+    y = K.linear(xd, wd, bd, relu=relu)
+    y2 = K.linear(xd, wd, bd, relu=relu)
+    u = K.linear(xd, wd, bd, relu=relu, routing=K.default_routing().replace(splitk=False))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    scale = float(ref.abs().max())
+    e, eu = float((y.cpu().double() - ref).abs().max()) / scale, float((u.cpu().double() - ref).abs().max()) / scale
+    print(f"split-K linear [{M},{Kdim}]->{Nout}: max err / range = {e:.2e} (single slice {eu:.2e})")
+    assert e <= 2e-6 and float((y - u).abs().max()) <= 1e-5 * scale      # (the single slice is the LESS accurate one: one long fp32 chain)
+    # layers the split does not take: a grid that already fills the chip, a short K
+    assert K._splitk_slices(K.default_routing(), 8192, 2048, 2048, 512) == 0 and K._splitk_slices(K.default_routing(), 100, 256, 256, 256) == 0
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64, 256, 256, 3, 1, 1, True), (1, 32, 32, 512, 512, 3, 1, 1, False), (1, 32, 32, 2048, 512, 1, 1, 0, False),
+                                   (2, 16, 16, 256, 72, 3, 1, 1, False), (1, 64, 64, 1024, 512, 1, 2, 0, False), (3, 16, 33, 256, 256, 3, 1, 1, True)])
+def test_conv_splitk_matches_the_single_slice_kernel(shape):
+    """the same split on convolutions (res4 / res5 3x3 and 1x1 layers, strided 1x1 shortcuts, the RPN head on small levels -
+    what one image per call leaves of the trunk): a slice starts in the middle of the (tap, channel) walk; residual + ReLU
+    and a channel-offset output go through the reduction kernel."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    N, H, W, Cin, Cout, k, stride, pad, res = shape
+    x = _rand((N, H, W, Cin), 61).to(dev)
+    w = _rand((Cout, k, k, Cin), 62, (2.0 / (k * k * Cin)) ** 0.5).to(dev)
+    b = _rand((Cout,), 63, 0.1).to(dev)
+    Ho, Wo = K.conv_out_size(H, W, k, k, stride, pad)
+    r = _rand((N, Ho, Wo, Cout), 64).to(dev) if res else None
+    on, off = K.default_routing().replace(winograd=False, pw=False), K.default_routing().replace(winograd=False, pw=False, splitk=False)
+    nk = k * k * Cin // 32
+    forced = [s_ for s_ in (3, 4, 6, 8, 2) if nk % s_ == 0][0]       # (the cost model decides in production; every count must be right)
+    out_a = torch.zeros((N, Ho, Wo, Cout + 8), device=dev)
+    out_b = torch.zeros((N, Ho, Wo, Cout + 8), device=dev)
+    rule = K._splitk_slices
+    K._splitk_slices = lambda *a_: forced
+    try:
+        a = K.conv2d_nhwc(x, w, b, stride=stride, padding=pad, relu=1, residual=r, res_mode=1 if res else 0, out=out_a, out_coff=4, routing=on)
+    finally:
+        K._splitk_slices = rule
+    u = K.conv2d_nhwc(x, w, b, stride=stride, padding=pad, relu=1, residual=r, res_mode=1 if res else 0, out=out_b, out_coff=4, routing=off)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), b.double().cpu(), stride=stride, padding=pad)
+    ref = ref.permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.double().cpu()
+    ref = F.relu(ref)
+    scale = float(ref.abs().max())
+    e = float((a[..., 4:4 + Cout].double().cpu() - ref).abs().max()) / scale
+    assert e <= 3e-6, e
+    assert float((a - u).abs().max()) <= 3e-6 * scale
+    assert float(a[..., :4].abs().max()) == 0.0 and float(a[..., 4 + Cout:].abs().max()) == 0.0      # the window's neighbours untouched
+
+
 def test_backbone_stem_fused_matches_the_two_launches_and_torch():
     """glass_backbone_stem_fused (conv 7x7 s2 p3 + bias + ReLU + max_pool2d(3, 2, 1) in one kernel, csrc/backbone_stem.hip) against
     the two launches it replaces and, on the smaller shapes, against torch CPU fp64 - shapes that cross the kernel's seams: more
