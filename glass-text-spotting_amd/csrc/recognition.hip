@@ -558,35 +558,6 @@ __global__ __launch_bounds__(256) void dec_gru_kernel(DecParams p, const float* 
   }
 }
 
-// reference early break (prediction_aster.py:91-93): after step i, if every RoI of the call has
-// emitted `eos` at least once the loop stops and later rows stay zero.  One workgroup per image.
-__global__ void decode_break_mask_kernel(const int* __restrict__ pred, const int* __restrict__ roi_image, int R, int max_len,
-                                         int C, int eos, float* __restrict__ out) {
-  __shared__ int s_lo, s_hi, s_break;
-  const int img = blockIdx.x;
-  if (threadIdx.x == 0) { s_lo = R; s_hi = -1; s_break = -1; }
-  __syncthreads();
-  for (int r = threadIdx.x; r < R; r += blockDim.x)
-    if (roi_image[r] == img) { atomicMin(&s_lo, r); atomicMax(&s_hi, r); }
-  __syncthreads();
-  if (s_hi < 0) return;
-  const int lo = s_lo, hi = s_hi;
-  for (int r = lo + threadIdx.x; r <= hi; r += blockDim.x) {
-    int first = max_len;   // first step with pred == eos (max_len: never)
-    for (int t = 0; t < max_len; ++t)
-      if (pred[(long)r * max_len + t] == eos) { first = t; break; }
-    atomicMax(&s_break, first);
-  }
-  __syncthreads();
-  const int brk = s_break;   // loop ran steps 0..brk (inclusive) if brk < max_len
-  if (brk >= max_len - 1) return;
-  const long per_row = (long)(max_len - 1 - brk) * C;
-  for (int r = lo; r <= hi; ++r) {
-    float* o = out + ((long)r * max_len + brk + 1) * C;
-    for (long i = threadIdx.x; i < per_row; i += blockDim.x) o[i] = 0.f;
-  }
-}
-
 extern "C" int64_t glass_decode_workspace_bytes(int R, int D) {
   return (int64_t)((size_t)R * D * 2 + (size_t)R * 2 * D) * sizeof(float) + (int64_t)R * sizeof(int);
 }

@@ -274,3 +274,381 @@ extern "C" int glass_bilstm_recurrence_persistent(const float* xg, const float* 
   GLASS_CHECK_LAUNCH("glass_bilstm_recurrence_persistent");
   return GLASS_OK;
 }
+
+// ================================================================== greedy attention-GRU decoder, one launch
+// Reference: AttentionRecognitionHead.sample (glass/modeling/recognition/prediction_aster.py:63-99), AttentionUnit :247-266,
+// DecoderUnit :291-302.  recognition.hip runs a decoding step as two launches (dec_fc_att_kernel, dec_gru_kernel) that re-stream
+// 2.7 MB of weights from L2 per RoI group and step: 24 us per step, 0.64 ms per image of a 7.9 ms one-image step.  Here a
+// group of 16 RoIs is served by a SET of 16 workgroups for all max_len steps; workgroup j of the set owns
+//   * rows [16 j, 16 j + 16) of every matrix that multiplies a vector of ALL 16 RoIs - the three GRU gates (W_hh and the
+//     context half W_ih[:, D:2D]) and sEmbed - as v_mfma_f32_16x16x4_f32 A fragments in registers, cut into K-quarters
+//     (wavefronts 4-7: W_hh and sEmbed, which need h_i only; wavefronts 0-3: the context half);
+//   * the attention, the classifier and the outputs of RoI j of the group: its x and xEmbed(x) rows in LDS (2 x 32 KB,
+//     step-invariant), fc streamed from L2 (97 KB per step, by wavefronts 0-3 while 4-7 run their MFMAs).
+// The embedding half of the GRU input needs no arithmetic at run time: W_ih[:, :D] emb[y] + b_ih is a [C, 3D] table
+// (`emb_gi`, built once at load), gathered by the arg-max.
+// Three hand-offs per step inside the set, all as 8-byte {step tag, value} granules (Guideline 16 R2), double-buffered by
+// step parity like the BiLSTM's: h_i (16 x 256 per consumer, from the owners of its unit slices), sEmbed(h_i) (256 per
+// consumer: a RoI's row from the 16 row owners) and ctx_i + arg-max (16 x 257, from the owners of the RoIs).  Step i:
+//   sweep h_i | W_hh h_i, sEmbed(h_i) (wavefronts 4-7) + fc(h_i[j]) partials (0-3) | publish sEmbed slice; soft-max / arg-max
+//   of step i-1's output (wavefront 4) | sweep sEmbed of RoI j | energies, soft-max, context | publish ctx_j |
+//   sweep ctx, y | W_ih[:, D:] ctx (wavefronts 0-3) | gates -> h_{i+1} slice, publish.
+// (A first form kept sEmbed's whole 256 x 256 matrix in 128 registers per thread and skipped the second hand-off: 44
+//  registers spilled to scratch and every phase paid for it - 32 K cycles per step.)
+// Start tickets, bounded spins and the status word are the BiLSTM kernel's (bit 1 of the status word).
+namespace {
+
+constexpr int PD_D = 256, PD_RB = 16, PD_UB = 16, PD_NS = PD_D / PD_UB;   // hidden size, RoIs per group, rows / workgroups per set
+constexpr int PD_T = 32, PD_CMAX = 128, PD_THREADS = 512;
+constexpr int PD_GRAN = PD_RB * PD_D;
+
+struct PdParams {
+  const float *x, *xproj;
+  const float *sW, *sB, *wW, *wB, *emb_gi, *w_ih, *w_hh, *b_hh, *fcW, *fcB;
+  float temperature;
+  int R, T, C, max_len, nsets;
+  float* out; int* pred;
+  unsigned long long *hgran, *cgran, *sgran, *ygran;   // per set: [parity][16 x 256] x 3, [parity][16]
+  unsigned* ctrl; int* status;
+};
+
+__device__ __forceinline__ unsigned long long granule(unsigned epoch, float v) {
+  return ((unsigned long long)epoch << 32) | __float_as_uint(v);
+}
+
+// 16 rows x (K-quarter kq) of a row-major matrix . the 16 RoI rows of `bs`: one 16 x 16 partial tile
+__device__ __forceinline__ f32x4 quarter_job(const float4 (&a)[4], const float (*bs)[PD_D + 4], int kq, int lane) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int S = 0; S < 4; ++S) {
+    const float4 b = *reinterpret_cast<const float4*>(&bs[lane & 15][64 * kq + 16 * S + 4 * (lane >> 4)]);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S].x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S].y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S].z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S].w, b.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams p) {
+  __shared__ __attribute__((aligned(16))) float hs[PD_RB][PD_D + 4];       // h_i of the group's 16 RoIs (B operand of W_hh, sEmbed)
+  __shared__ __attribute__((aligned(16))) float cs[PD_RB][PD_D + 4];       // ctx_i of the 16 RoIs (B operand of the context half)
+  __shared__ __attribute__((aligned(16))) float xs[PD_T][PD_D];            // x of this workgroup's RoI
+  __shared__ __attribute__((aligned(16))) float xps[PD_T][PD_D + 4];       // xEmbed(x) of this workgroup's RoI (+4: row skew, 16 lanes per row)
+  __shared__ float gpart[2][4][3][PD_RB][PD_UB];                            // [context | hidden][K-quarter][gate][RoI][unit]
+  __shared__ float spart[4][PD_RB][PD_UB];                                  // sEmbed: [K-quarter][RoI][row]
+  __shared__ __attribute__((aligned(16))) float sproj[PD_D];
+  __shared__ __attribute__((aligned(16))) float wws[PD_D];                  // wEmbed's weight row
+  __shared__ float energy[PD_T];
+  __shared__ float alpha[PD_THREADS / 64][PD_T];                            // per wavefront: its own copy of the attention weights
+  __shared__ float ctxp[2][PD_D];
+  __shared__ float logitp[2][PD_CMAX];
+  __shared__ unsigned s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_ticket = atomicAdd(p.ctrl, 1u);
+  __syncthreads();
+  const int set = (int)(s_ticket >> 4), j = (int)(s_ticket & 15);
+  if (set >= p.nsets) return;
+  const int T = p.T, C = p.C, L = p.max_len;
+  const int rr = set * PD_RB + j;                 // the RoI whose attention / classifier this workgroup runs
+  const bool roi_ok = rr < p.R;
+  gu64* const hg = (gu64*)p.hgran + (long)set * 2 * PD_GRAN;
+  gu64* const cg = (gu64*)p.cgran + (long)set * 2 * PD_GRAN;
+  gu64* const sg = (gu64*)p.sgran + (long)set * 2 * PD_GRAN;
+  gu64* const yg = (gu64*)p.ygran + (long)set * 2 * PD_RB;
+
+  // ---- resident operands: wavefront w = (part = w >> 2: 0 the context half W_ih[:, D:2D], 1 W_hh + sEmbed; K-quarter w & 3)
+  const int part = wave >> 2, kq = wave & 3;
+  float4 ga[3][4], sa[4];
+  {
+    const float* Wp = part == 0 ? p.w_ih + PD_D : p.w_hh;
+    const int ld = part == 0 ? 2 * PD_D : PD_D;
+    const int koff = 64 * kq + 4 * (lane >> 4);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int S = 0; S < 4; ++S) {
+        ga[g][S] = *reinterpret_cast<const float4*>(Wp + (long)(g * PD_D + j * PD_UB + (lane & 15)) * ld + koff + 16 * S);
+        asm volatile("" : "+v"(ga[g][S].x), "+v"(ga[g][S].y), "+v"(ga[g][S].z), "+v"(ga[g][S].w));
+      }
+#pragma unroll
+    for (int S = 0; S < 4; ++S) {
+      sa[S] = *reinterpret_cast<const float4*>(p.sW + (long)(j * PD_UB + (lane & 15)) * PD_D + koff + 16 * S);
+      asm volatile("" : "+v"(sa[S].x), "+v"(sa[S].y), "+v"(sa[S].z), "+v"(sa[S].w));
+    }
+  }
+  // the RoI's step-invariant rows
+  for (int i = tid; i < PD_T * (PD_D / 4); i += PD_THREADS) {
+    const int t = i / (PD_D / 4), d4 = i % (PD_D / 4);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (roi_ok && t < T) {
+      a = reinterpret_cast<const float4*>(p.x + ((long)rr * T + t) * PD_D)[d4];
+      b = reinterpret_cast<const float4*>(p.xproj + ((long)rr * T + t) * PD_D)[d4];
+    }
+    *reinterpret_cast<float4*>(&xs[t][d4 * 4]) = a;
+    *reinterpret_cast<float4*>(&xps[t][d4 * 4]) = b;
+  }
+  for (int i = tid; i < PD_RB * (PD_D + 4); i += PD_THREADS) (&hs[0][0])[i] = 0.f;        // h_0 = 0
+  if (tid < PD_D) wws[tid] = p.wW[tid];
+  // element (RoI row pr, row / unit pu of this workgroup's 16) of the threads that finish the row-owner products
+  const int pr = (tid >> 4) & 15, pu = tid & 15, u = j * PD_UB + pu;
+  const float bh0 = p.b_hh[u], bh1 = p.b_hh[PD_D + u], bh2 = p.b_hh[2 * PD_D + u], sbias = p.sB[u];
+  const float wbias = p.wB[0];
+  bool dead = false;
+  __syncthreads();
+#ifdef GLASS_PL_STAMPS
+  unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define PD_STAMP(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); st[k] += tn - tlast; tlast = tn; }
+#else
+#define PD_STAMP(k)
+#endif
+
+  for (int i = 0; i <= L; ++i) {
+    // ---- A: h_i of the whole group (h_0 = 0 is in LDS already)
+    if (i > 0) {
+      unsigned long long v[8];
+      const gu64* src = hg + (i & 1) * PD_GRAN;
+      sweep_issue(src, tid, v);
+      sweep_finish(src, (unsigned)i, tid, lane, v, hs, dead, p.status, 2);
+    }
+    lds_barrier();
+    PD_STAMP(0)
+    const float hprev = hs[pr][u];                  // for the cell update at the end of the step
+    // ---- B: wavefronts 4-7: W_hh h_i and sEmbed(h_i) for the 16 RoIs (this workgroup's 16 rows, one K-quarter each);
+    //         wavefronts 0-3: classifier partial sums on h_i of this RoI (= the output of step i - 1)
+    if (part == 1) {
+      if (i < L) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const f32x4 acc = quarter_job(ga[g], hs, kq, lane);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gpart[1][kq][g][lane & 15][(lane >> 4) * 4 + e] = acc[e];
+        }
+        const f32x4 acc = quarter_job(sa, hs, kq, lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) spart[kq][lane & 15][(lane >> 4) * 4 + e] = acc[e];
+      }
+    } else if (i > 0) {
+      const int c = tid & 127, q = tid >> 7;        // class, K half
+      float acc = 0.f;
+      if (c < C) {
+#pragma unroll 1
+        for (int b = 0; b < 4; ++b) {
+          float4 w8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w8[e] = reinterpret_cast<const float4*>(p.fcW)[(long)(32 * q + 8 * b + e) * C + c];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float4 hv = *reinterpret_cast<const float4*>(&hs[j][4 * (32 * q + 8 * b + e)]);
+            acc += w8[e].x * hv.x + w8[e].y * hv.y + w8[e].z * hv.z + w8[e].w * hv.w;
+          }
+        }
+      }
+      logitp[q][c] = acc;
+    }
+    lds_barrier();
+    PD_STAMP(1)
+    // ---- publish this workgroup's rows of sEmbed(h_i) (threads 0-255); wavefront 4: soft-max / arg-max of step i - 1
+    if (tid < PD_RB * PD_UB) {
+      if (i < L) {
+        const float sv = ((spart[0][pr][pu] + spart[1][pr][pu]) + (spart[2][pr][pu] + spart[3][pr][pu])) + sbias;
+        __hip_atomic_store(sg + (i & 1) * PD_GRAN + pr * PD_D + u, granule((unsigned)(i + 1), sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (wave == 4) {
+      if (i > 0) {
+        float vv[2], m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = lane + 64 * e;
+          vv[e] = c < C ? (p.fcB[c] + (logitp[0][c] + logitp[1][c])) * p.temperature : -INFINITY;
+          m = fmaxf(m, vv[e]);
+        }
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { vv[e] = (lane + 64 * e) < C ? expf(vv[e] - m) : 0.f; s += vv[e]; }
+        s = wave_sum(s);
+        float best = -1.f;
+        int besti = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = lane + 64 * e;
+          if (c < C) {
+            const float pv = vv[e] / s;
+            if (roi_ok) p.out[((long)rr * L + (i - 1)) * C + c] = pv;
+            if (pv > best) { best = pv; besti = c; }
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          const float ob = __shfl_xor(best, off);
+          const int oi = __shfl_xor(besti, off);
+          if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (lane == 0) {
+          if (roi_ok) p.pred[(long)rr * L + (i - 1)] = besti;
+          // the symbol of step i - 1 feeds step i: tagged i + 1 like the context it is consumed with
+          if (i < L) __hip_atomic_store(yg + (i & 1) * PD_RB + j, granule((unsigned)(i + 1), __int_as_float(roi_ok ? besti : 0)),
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else if (lane == 0) {
+        __hip_atomic_store(yg + j, granule(1u, __int_as_float(0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // before step 0: [GO]
+      }
+    }
+    if (i == L) break;
+    // ---- C: sEmbed(h_i) of THIS RoI, one row from each of the 16 row owners (threads 0-255: one granule each)
+    if (tid < PD_D) {
+      const gu64* src = sg + (i & 1) * PD_GRAN + j * PD_D + tid;
+      unsigned spins = 0;
+      unsigned long long sv;
+      for (;;) {
+        sv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((unsigned)(sv >> 32) == (unsigned)(i + 1)) || dead) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > PL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(p.status, 2); }
+      }
+      sproj[tid] = __uint_as_float((unsigned)sv);
+    }
+    lds_barrier();
+    PD_STAMP(2)
+    //      energies e[t] = wEmbed(tanh(sProj + xProj[t])): thread (t = tid >> 4, 16 channels 4 dq + 64 m), 16 lanes per t
+    {
+      const int t = tid >> 4, dq = tid & 15;
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float4 sp = *reinterpret_cast<const float4*>(&sproj[64 * m + 4 * dq]);
+        const float4 xp = *reinterpret_cast<const float4*>(&xps[t][64 * m + 4 * dq]);
+        const float4 wq = *reinterpret_cast<const float4*>(&wws[64 * m + 4 * dq]);
+        s += wq.x * tanh_fast(sp.x + xp.x) + wq.y * tanh_fast(sp.y + xp.y) + wq.z * tanh_fast(sp.z + xp.z) + wq.w * tanh_fast(sp.w + xp.w);
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (dq == 0) energy[t] = s + wbias;
+    }
+    lds_barrier();
+    PD_STAMP(3)
+    //      soft-max over T, every wavefront for itself (its own LDS copy: no barrier), then context = alpha . x:
+    //      thread (channel d = tid & 255, time half = tid >> 8)
+    {
+      const float v = lane < T ? energy[lane & (PD_T - 1)] : -INFINITY;
+      const float m = wave_max(v);
+      const float e = lane < T ? expf(v - m) : 0.f;
+      const float s = wave_sum(e);
+      if (lane < PD_T) alpha[wave][lane] = e / s;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int d = tid & 255, th = tid >> 8;
+      float c = 0.f;
+#pragma unroll
+      for (int t = 0; t < PD_T / 2; ++t) c += alpha[wave][2 * t + th] * xs[2 * t + th][d];
+      ctxp[th][d] = c;
+    }
+    lds_barrier();
+    PD_STAMP(4)
+    if (tid < PD_D)
+      __hip_atomic_store(cg + (i & 1) * PD_GRAN + j * PD_D + tid, granule((unsigned)(i + 1), roi_ok ? ctxp[0][tid] + ctxp[1][tid] : 0.f),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- E: the contexts and symbols of the whole group
+    float eg0 = 0.f, eg1 = 0.f, eg2 = 0.f;
+    {
+      unsigned long long v[8];
+      const gu64* src = cg + (i & 1) * PD_GRAN;
+      sweep_issue(src, tid, v);
+      sweep_finish(src, (unsigned)(i + 1), tid, lane, v, cs, dead, p.status, 2);
+      PD_STAMP(5)
+      // the symbols: thread (pr, pu) needs y of RoI pr for its row of the embedding table
+      if (tid < PD_RB * PD_UB) {
+        unsigned spins = 0;
+        unsigned long long yv;
+        for (;;) {
+          yv = __hip_atomic_load(yg + (i & 1) * PD_RB + pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all((unsigned)(yv >> 32) == (unsigned)(i + 1)) || dead) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > PL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(p.status, 2); }
+        }
+        int y = (int)(unsigned)yv;
+        y = min(max(y, 0), C - 1);
+        const float* er = p.emb_gi + (long)y * (3 * PD_D) + u;
+        eg0 = er[0]; eg1 = er[PD_D]; eg2 = er[2 * PD_D];          // in flight during the context half's MFMAs
+      }
+    }
+    lds_barrier();
+    PD_STAMP(6)
+    // ---- F: context half (wavefronts 0-3), then the cell update
+    if (part == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const f32x4 acc = quarter_job(ga[g], cs, kq, lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gpart[0][kq][g][lane & 15][(lane >> 4) * 4 + e] = acc[e];
+      }
+    }
+    lds_barrier();
+    PD_STAMP(7)
+    if (tid < PD_RB * PD_UB) {
+      float gi[3], gh[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        gi[g] = (gpart[0][0][g][pr][pu] + gpart[0][1][g][pr][pu]) + (gpart[0][2][g][pr][pu] + gpart[0][3][g][pr][pu]);
+        gh[g] = (gpart[1][0][g][pr][pu] + gpart[1][1][g][pr][pu]) + (gpart[1][2][g][pr][pu] + gpart[1][3][g][pr][pu]);
+      }
+      const float rg = sigmoid_fast((gi[0] + eg0) + (gh[0] + bh0));
+      const float zg = sigmoid_fast((gi[1] + eg1) + (gh[1] + bh1));
+      const float ng = tanh_fast((gi[2] + eg2) + rg * (gh[2] + bh2));
+      const float hn = (1.f - zg) * ng + zg * hprev;
+      __hip_atomic_store(hg + ((i + 1) & 1) * PD_GRAN + pr * PD_D + u, granule((unsigned)(i + 1), hn), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    PD_STAMP(8)
+    // (no barrier here: the next step's sweep rewrites hs - read above only before barrier B - and its barrier A orders the
+    //  gpart / spart reads of this cell update before the next step's writes)
+  }
+#ifdef GLASS_PL_STAMPS
+  if (s_ticket == 0 && (tid == 0 || tid == 256))
+    for (int k = 0; k < 12; ++k) reinterpret_cast<unsigned long long*>(p.ctrl + 16)[k + (tid ? 12 : 0)] = st[k];
+#endif
+}
+
+}  // namespace
+
+extern "C" int64_t glass_decode_persistent_workspace_bytes(int R) {
+  const int64_t sets = cdiv(R, PD_RB);
+  return (int64_t)PL_CTRL_BYTES + sets * (3 * 2 * PD_GRAN + 2 * PD_RB) * (int64_t)sizeof(unsigned long long);
+}
+
+extern "C" int glass_decode_persistent_supported(int T, int D, int C, int max_len) {
+  return D == PD_D && T > 0 && T <= PD_T && C > 0 && C <= PD_CMAX && max_len > 0;
+}
+
+extern "C" int glass_attention_decode_persistent(const float* x, const float* xproj, const glass_decoder_weights* w,
+                                                 const float* sW_rowmajor, const float* emb_gi, const int* roi_image, int R,
+                                                 int num_images, int T, int D, int C, int max_len, int eos, float* out,
+                                                 int* pred_scratch, void* workspace, int64_t workspace_bytes, glass_stream_t stream) {
+  GLASS_CHECK_ARG(glass_decode_persistent_supported(T, D, C, max_len),
+                  "glass_attention_decode_persistent: needs D=256, T<=32, C<=128 (got D=%d T=%d C=%d)", D, T, C);
+  if (R == 0) return GLASS_OK;
+  GLASS_CHECK_ARG(x && xproj && w && sW_rowmajor && emb_gi && roi_image && out && pred_scratch && num_images > 0 && workspace,
+                  "glass_attention_decode_persistent: null pointer");
+  GLASS_CHECK_ARG(workspace_bytes >= glass_decode_persistent_workspace_bytes(R), "glass_attention_decode_persistent: workspace too small");
+  GLASS_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "glass_attention_decode_persistent: workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  PdParams p;
+  p.x = x; p.xproj = xproj; p.sW = sW_rowmajor; p.sB = w->sB; p.wW = w->wW; p.wB = w->wB; p.emb_gi = emb_gi; p.w_ih = w->w_ih;
+  p.w_hh = w->w_hh; p.b_hh = w->b_hh; p.fcW = w->fcW; p.fcB = w->fcB; p.temperature = w->temperature;
+  p.R = R; p.T = T; p.C = C; p.max_len = max_len; p.nsets = cdiv(R, PD_RB); p.out = out; p.pred = pred_scratch;
+  char* ws = static_cast<char*>(workspace);
+  p.ctrl = reinterpret_cast<unsigned*>(ws);
+  p.hgran = reinterpret_cast<unsigned long long*>(ws + PL_CTRL_BYTES);
+  p.cgran = p.hgran + (size_t)p.nsets * 2 * PD_GRAN;
+  p.sgran = p.cgran + (size_t)p.nsets * 2 * PD_GRAN;
+  p.ygran = p.sgran + (size_t)p.nsets * 2 * PD_GRAN;
+  p.status = recurrence_status_word();
+  if (!p.status) { glass_set_error("glass_attention_decode_persistent: no status word (hipMalloc failed)"); return GLASS_EHIP; }
+  hipError_t e = hipMemsetAsync(workspace, 0, (size_t)glass_decode_persistent_workspace_bytes(R), s);
+  if (e != hipSuccess) { glass_set_error("glass_attention_decode_persistent: memset: %s", hipGetErrorString(e)); return GLASS_EHIP; }
+  hipLaunchKernelGGL(decode_persistent_kernel, dim3(p.nsets * PD_NS), dim3(PD_THREADS), 0, s, p);
+  GLASS_CHECK_LAUNCH("glass_attention_decode_persistent");
+  hipLaunchKernelGGL(decode_break_mask_kernel, dim3(num_images), dim3(256), 0, s, pred_scratch, roi_image, R, max_len, C, eos, out);
+  GLASS_CHECK_LAUNCH("glass_attention_decode_persistent(mask)");
+  return GLASS_OK;
+}

@@ -29,6 +29,7 @@ EXPORTS = [
     "glass_rpn_workspace_bytes", "glass_rpn_topk_decode", "glass_rotated_nms_select", "glass_pairwise_iou_rotated", "glass_detections_finalize", "glass_postprocess_words", "glass_text_argmax",
     "glass_box_decode", "glass_gc_attention_inplace", "glass_mean_over_h", "glass_bilstm_workspace_bytes", "glass_bilstm_recurrence",
     "glass_bilstm_persistent_workspace_bytes", "glass_bilstm_recurrence_persistent", "glass_recurrence_status",
+    "glass_decode_persistent_supported", "glass_decode_persistent_workspace_bytes", "glass_attention_decode_persistent",
     "glass_decode_workspace_bytes", "glass_attention_decode", "glass_decode_step_workspace_bytes", "glass_attention_decode_step",
 ]
 
@@ -117,6 +118,7 @@ def lib() -> ctypes.CDLL:
         L.glass_conv_h16_weight_halves.restype = ctypes.c_size_t
         L.glass_bilstm_workspace_bytes.restype = ctypes.c_int64
         L.glass_bilstm_persistent_workspace_bytes.restype = ctypes.c_int64
+        L.glass_decode_persistent_workspace_bytes.restype = ctypes.c_int64
         L.glass_decode_workspace_bytes.restype = ctypes.c_int64
         L.glass_decode_step_workspace_bytes.restype = ctypes.c_int64
         L.glass_conv2d_splitk_workspace_bytes.restype = ctypes.c_int64

@@ -1,5 +1,7 @@
-"""Attention decoder (`ASTER_V2` -> `AttentionRecognitionHead.sample`) behind ONE ABI call (glass_attention_decode: two kernels per
-decoding step spread over the chip, arg-max feedback on the device, the per-image early break applied by a mask kernel afterwards).
+"""Attention decoder (`ASTER_V2` -> `AttentionRecognitionHead.sample`) behind ONE ABI call: glass_attention_decode_persistent (ONE
+launch for all steps: GRU rows and sEmbed resident in registers, h / context handed between the 16 workgroups of a 16-RoI group
+inside the launch) or, with Routing.rnn == "steps", glass_attention_decode (two kernels per decoding step spread over the chip);
+arg-max feedback on the device, the per-image early break applied by a mask kernel afterwards.
 
 Mirrors reference glass/modeling/recognition/recognizer_decoder.py:65-93 and
 prediction_aster.py:63-99 (greedy sampling, eos index 0, pre-zeroed [R,26,97] output with
@@ -54,6 +56,12 @@ class ASTER_V2(InferenceModule):
             "fcB": dev(f("fc.bias"), device),
             "temperature": float(sd[q + "temperature"].reshape(-1)[0]) if (q + "temperature") in sd else 1.0,
         }
+        # the one-launch decoder (glass_attention_decode_persistent): sEmbed as torch stores it, and the embedding half of the
+        # GRU input as a table - W_ih[:, :D] emb[c] + b_ih for every class c, computed once (fp64, stored fp32)
+        D = f("gru.weight_hh_l0").shape[1]
+        self.w["sW_rm"] = dev(f("attention_unit.sEmbed.weight").contiguous(), device)
+        self.w["emb_gi"] = dev((f("tgt_embedding.weight").double() @ f("gru.weight_ih_l0")[:, :D].double().t()
+                                + f("gru.bias_ih_l0").double()).float().contiguous(), device)
 
     def beam_search(self, x: torch.Tensor, beam_width: int, eos: int = 0):
         """`AttentionRecognitionHead.beam_search` (reference prediction_aster.py:101-222; never called by the reference's
@@ -135,4 +143,5 @@ class ASTER_V2(InferenceModule):
             roi_image = torch.zeros((R,), dtype=torch.int32, device=x.device)
             num_images = 1
         xproj = K.linear(x.view(R * T, D), self.w["xW"], self.w["xB"]).view(R, T, D)
-        return K.attention_decode(x, xproj, self.w, roi_image, num_images, self.num_classes, self.max_word_len, 0)
+        return K.attention_decode(x, xproj, self.w, roi_image, num_images, self.num_classes, self.max_word_len, 0,
+                                  mode=K.routing_of(self.w["xW"]).rnn)

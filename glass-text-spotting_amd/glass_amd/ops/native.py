@@ -949,8 +949,11 @@ def recurrence_status(reset: bool = True) -> int:
 
 
 def attention_decode(x: torch.Tensor, xproj: torch.Tensor, weights: dict, roi_image: torch.Tensor, num_images: int,
-                     num_classes: int, max_len: int, eos: int) -> torch.Tensor:
-    """x, xproj [R,T,D]; weights: dict of packed device tensors + 'temperature' float."""
+                     num_classes: int, max_len: int, eos: int, mode=None) -> torch.Tensor:
+    """x, xproj [R,T,D]; weights: dict of packed device tensors + 'temperature' float.  `mode` as in bilstm_recurrence:
+    "steps" = two launches per decoding step (glass_attention_decode); anything else = ONE launch for all steps
+    (glass_attention_decode_persistent: needs weights["sW_rm"], weights["emb_gi"] and a shape it supports, else the step
+    kernels run); None = the raw-tensor default routing's `rnn`."""
     _f32c(x, "x"); _f32c(xproj, "xproj"); _i32(roi_image, "roi_image")
     R, T, D = x.shape
     out = torch.empty((R, max_len, num_classes), dtype=torch.float32, device=x.device)
@@ -961,6 +964,17 @@ def attention_decode(x: torch.Tensor, xproj: torch.Tensor, weights: dict, roi_im
     for n in ("sW", "sB", "wW", "wB", "emb", "w_ih", "w_hh", "b_ih", "b_hh", "fcW", "fcB"):
         setattr(w, n, _dev(_f32c(weights[n], n)))
     w.temperature = float(weights["temperature"])
+    mode = _DEFAULT.rnn if mode is None else mode
+    if (mode != "steps" and "sW_rm" in weights and "emb_gi" in weights and
+            lib().glass_decode_persistent_supported(T, D, int(num_classes), int(max_len))):
+        nbytes = int(lib().glass_decode_persistent_workspace_bytes(R))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        check(lib().glass_attention_decode_persistent(
+            c_void_p(_dev(x)), c_void_p(_dev(xproj)), ctypes.byref(w), c_void_p(_dev(_f32c(weights["sW_rm"], "sW_rm"))),
+            c_void_p(_dev(_f32c(weights["emb_gi"], "emb_gi"))), c_void_p(_dev(roi_image)), R, int(num_images), T, D, int(num_classes),
+            int(max_len), int(eos), c_void_p(_dev(out)), c_void_p(_dev(pred)), c_void_p(_dev(ws)), ctypes.c_int64(nbytes),
+            c_void_p(stream_handle())), "glass_attention_decode_persistent")
+        return out
     nbytes = int(lib().glass_decode_workspace_bytes(R, D))
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     check(lib().glass_attention_decode(c_void_p(_dev(x)), c_void_p(_dev(xproj)), ctypes.byref(w), c_void_p(_dev(roi_image)),

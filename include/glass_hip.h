@@ -426,6 +426,22 @@ int glass_attention_decode(const float* x, const float* xproj, const glass_decod
                            int num_images, int T, int D, int C, int max_len, int eos, float* out, int* pred_scratch,
                            void* workspace, int64_t workspace_bytes, glass_stream_t stream);
 
+/* The same decoder as ONE launch for all max_len steps (csrc/recurrent_persistent.hip; same reference lines and outputs up to
+ * fp32 summation order): a group of 16 RoIs is served by 16 workgroups that keep the GRU rows of 16 hidden units each (W_hh
+ * and the context half of W_ih as MFMA fragments) and sEmbed in registers, one RoI's x / xproj rows in LDS, and hand h_i and
+ * (context_i, arg-max) to each other inside the launch as 8-byte {step tag, value} device-scope granules.  Extra operands,
+ * built once at load: sW_rowmajor [D][D] (sEmbed.weight as stored by torch; `w->sW` is not read) and emb_gi [C][3D] =
+ * tgt_embedding.weight @ W_ih[:, :D]^T + b_ih (the embedding half of the GRU input needs no arithmetic per step; `w->emb`,
+ * `w->b_ih` are not read).  Needs D == 256, T <= 32, C <= 128 (glass_decode_persistent_supported); `workspace` (16-byte
+ * aligned, >= glass_decode_persistent_workspace_bytes) is zeroed by the call.  Bounded waits: bit 1 of
+ * glass_recurrence_status.  Two launches (decoder, early-break mask).                                              */
+int glass_decode_persistent_supported(int T, int D, int C, int max_len);
+int64_t glass_decode_persistent_workspace_bytes(int R);
+int glass_attention_decode_persistent(const float* x, const float* xproj, const glass_decoder_weights* w, const float* sW_rowmajor,
+                                      const float* emb_gi, const int* roi_image, int R, int num_images, int T, int D, int C,
+                                      int max_len, int eos, float* out, int* pred_scratch, void* workspace,
+                                      int64_t workspace_bytes, glass_stream_t stream);
+
 /* ONE step of the same decoder for a search driven by the caller - `output, state, alpha = self.decoder(x, state, y_prev)`
  * inside AttentionRecognitionHead.beam_search (glass/modeling/recognition/prediction_aster.py:133-134, DecoderUnit.forward
  * :291-302): additive attention with the state h_in [R,D] -> context, embedding of y_prev [R] (ints), GRU cell -> h_out

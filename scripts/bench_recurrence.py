@@ -61,4 +61,37 @@ for R in Rs:
             K.conv2d_nhwc(x, w, None, padding=1, out=yc)
     torch.cuda.synchronize()
     print(f"          (40 convs alone: {(time.perf_counter() - t0) * 1e3:7.2f} ms)")
+# ---- decoder
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from glass_amd.config import get_glass_cfg
+from glass_amd.modeling.recognition.recognizer_decoder import ASTER_V2
+from glass_amd.structures.core import ShapeSpec
+from glass_amd.utils.synth import make_state_dict
+cfg = get_glass_cfg(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "configs", "glass_icdar15_mi355x.yaml"))
+dec = ASTER_V2(cfg, ShapeSpec(channels=256))
+dec.import_weights(make_state_dict(1234), dev, "roi_heads.recognizer_head.decoder.")
+for R in Rs:
+    g = torch.Generator().manual_seed(R)
+    xd = torch.randn((R, 32, 256), generator=g).to(dev)
+    ri = (torch.arange(R) // 32).to(torch.int32).to(dev)
+    ni = int(ri.max()) + 1
+    xp = K.linear(xd.view(R * 32, 256), dec.w["xW"], dec.w["xB"]).view(R, 32, 256)
+    ref = K.attention_decode(xd, xp, dec.w, ri, ni, dec.num_classes, dec.max_word_len, 0, mode="steps")
+    for mode in ("steps", (1, 1)):
+        out = K.attention_decode(xd, xp, dec.w, ri, ni, dec.num_classes, dec.max_word_len, 0, mode=mode)
+        err = float((out - ref).abs().max())
+        t_alone = timeit(lambda: K.attention_decode(xd, xp, dec.w, ri, ni, dec.num_classes, dec.max_word_len, 0, mode=mode), n=20)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                K.conv2d_nhwc(x, w, None, padding=1, out=yc)
+        e0.record()
+        for _ in range(10):
+            K.attention_decode(xd, xp, dec.w, ri, ni, dec.num_classes, dec.max_word_len, 0, mode=mode)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"decoder R={R:5d} mode={str(mode):8s} max |diff| vs steps {err:.2e}  alone {t_alone:8.1f} us   beside 40 convs: {e0.elapsed_time(e1) / 10 * 1e3:8.1f} us, "
+              f"everything done in {(time.perf_counter() - t0) * 1e3:7.2f} ms")
 print("status", K.recurrence_status())

@@ -65,3 +65,74 @@ def test_persistent_bilstm_under_uneven_load():
 def test_encoder_module_takes_the_persistent_path_by_default():
     from glass_amd.ops import native as K
     assert K.Routing().rnn == (1, 1) and K.Routing(rnn="persistent").rnn == "persistent" and K.Routing(rnn="steps").rnn == "steps" and K.Routing(rnn="2x2").rnn == (2, 2)
+
+
+def _decoder(cfg_path_args=()):
+    import os
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.modeling.recognition.recognizer_decoder import ASTER_V2
+    from glass_amd.structures.core import ShapeSpec
+    from glass_amd.utils.synth import make_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_glass_cfg(os.path.join(root, "configs", "glass_icdar15_mi355x.yaml"))
+    sd = make_state_dict(1234)
+    dec = ASTER_V2(cfg, ShapeSpec(channels=256))
+    dec.import_weights(sd, _dev(), "roi_heads.recognizer_head.decoder.")
+    return dec, sd
+
+
+@pytest.mark.parametrize("R", [1, 16, 37, 256, 530])
+def test_persistent_decoder_matches_the_step_kernels(R):
+    """glass_attention_decode_persistent vs glass_attention_decode on the same inputs: the same arithmetic in another summation
+    order (K-quarters of the GRU, two halves of sEmbed, the embedding half as a table), so probabilities agree to 1e-5 wherever
+    the greedy arg-max took the same branch; RoIs whose two best classes are closer than fp32 rounding at some step are
+    compared up to that step (as tests/test_gpu_a_stages.py does against the oracle).  Includes the per-image early break."""
+    import numpy as np
+    from glass_amd.ops import native as K
+    dec, _ = _decoder()
+    g = torch.Generator().manual_seed(300 + R)
+    x = torch.randn((R, 32, 256), generator=g).to(_dev())
+    cuts = [R // 5, R // 5 + R // 2]
+    ri = torch.zeros((R,), dtype=torch.int32)
+    ri[cuts[0]:cuts[1]] = 1
+    ri[cuts[1]:] = 2
+    ri = ri.to(_dev())
+    xproj = K.linear(x.view(R * 32, 256), dec.w["xW"], dec.w["xB"]).view(R, 32, 256)
+    ref = K.attention_decode(x, xproj, dec.w, ri, 3, dec.num_classes, dec.max_word_len, 0, mode="steps").cpu().numpy()
+    for rep in range(3):
+        got = K.attention_decode(x, xproj, dec.w, ri, 3, dec.num_classes, dec.max_word_len, 0, mode=(1, 1)).cpu().numpy()
+        assert K.recurrence_status() == 0
+        srt = np.sort(ref, axis=-1)
+        near_tie = (srt[..., -1] - srt[..., -2]) < 1e-5
+        live = ref.sum(-1) > 0
+        first_tie = np.where((near_tie & live).any(1), (near_tie & live).argmax(1), 26)
+        mask = np.arange(26)[None, :] <= first_tie[:, None]
+        assert (first_tie < 26).mean() < 0.02
+        err = float(np.abs(got - ref)[mask].max())
+        assert err < 1e-5, (rep, err)
+        assert ((got.sum(-1) == 0) == (ref.sum(-1) == 0))[first_tie == 26].all(), "early-break zero rows differ"
+
+
+def test_persistent_decoder_under_uneven_load():
+    import numpy as np
+    from glass_amd.ops import native as K
+    dec, _ = _decoder()
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((256, 32, 256), generator=g).to(dev)
+    ri = (torch.arange(256) // 32).to(torch.int32).to(dev)
+    xproj = K.linear(x.view(256 * 32, 256), dec.w["xW"], dec.w["xB"]).view(256, 32, 256)
+    ref = K.attention_decode(x, xproj, dec.w, ri, 8, dec.num_classes, dec.max_word_len, 0, mode=(1, 1))
+    xc = torch.randn((8, 128, 128, 256), device=dev)
+    wc = K.prepare_conv_weights(torch.randn((256, 3, 3, 256), device=dev) * 0.05, "fp32")
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    bad = 0
+    for rep in range(20):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 4):
+                K.conv2d_nhwc(xc, wc, None, padding=1)
+        got = K.attention_decode(x, xproj, dec.w, ri, 8, dec.num_classes, dec.max_word_len, 0, mode=(1, 1))
+        bad += int(not torch.equal(got, ref))          # the same kernel on the same inputs: bit-identical whatever the timing
+    torch.cuda.synchronize()
+    assert bad == 0 and K.recurrence_status() == 0
