@@ -206,7 +206,7 @@ def test_device_postprocessor_equals_host_restatement_with_text():
 
 def test_postprocess_words_regression_fixture(golden_dir):
     """The word post-processor's outputs on committed detections (the bench's 8 images, dense scenes of 100 / 128 boxes with random
-    scores, un-scaling, ragged counts) are EXACTLY those of the fixture (scripts/make_pp_regression.py: written by the round-4 kernel;
+    scores, un-scaling, ragged counts) are those of the fixture - discrete outputs exactly, floats to a few ulp (scripts/make_pp_regression.py: written by the round-4 kernel;
     the round-3 kernel - pinned on the host restatement above - reproduces it bit for bit when it, too, is compiled without FMA
     contraction, and so it does on the 160 scenes of scripts/fuzz_postprocess.py).  Guards the restructured merge loop: queued near
     pairs, 8 lanes per merge, the NMS IoU re-indexed into the next iteration's IoA, bit-mask suppression."""
@@ -220,10 +220,20 @@ def test_postprocess_words_regression_fixture(golden_dir):
         b, sc, cnt = (torch.from_numpy(g[f"{name}/in_{k}"]).to(dev) for k in ("boxes", "scores", "counts"))
         s = torch.from_numpy(g[f"{name}/in_scale_xy"]).to(dev) if f"{name}/in_scale_xy" in g.files else None
         o = K.postprocess_words(b, sc, cnt, pattern_text(*sc.shape).to(dev), s, [float(v) for v in g[f"{name}/thresholds"]], 94)
+        worst = 0.0
         for k, v in o.items():
-            assert np.array_equal(v.cpu().numpy(), g[f"{name}/out_{k}"]), (name, k)
+            got, want = v.cpu().numpy(), g[f"{name}/out_{k}"]
+            if np.issubdtype(want.dtype, np.floating):
+                # geometry goes through the device's sinf / cosf / atan2f / hypot: a ROCm or libdevice update may move a last
+                # bit without any regression - a few ulp of the value range, not bit equality
+                assert got.shape == want.shape, (name, k)
+                tol = 4 * np.finfo(np.float32).eps * max(1.0, float(np.abs(want).max()))
+                worst = max(worst, float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()) if want.size else 0.0)
+                np.testing.assert_allclose(got, want, rtol=0, atol=tol, err_msg=f"{name}/{k}")
+            else:
+                assert np.array_equal(got, want), (name, k)          # counts, source indices, characters, word lengths: exact
         assert int(o["count"].sum()) > 0
-        print(f"[post-processor regression] {name}: kept {o['count'].tolist()} (exact)")
+        print(f"[post-processor regression] {name}: kept {o['count'].tolist()} (discrete outputs exact, floats within 4 ulp of the range: max diff {worst:.2e})")
 
 
 def test_postprocess_words_with_50_character_words():

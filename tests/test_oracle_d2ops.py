@@ -202,9 +202,10 @@ def test_iou_against_independent_float64_clipping_sweep():
 
 
 def test_min_area_rect_known_answers():
-    """`cv2.minAreaRect` stand-in used by the word merge (post_processor_rotated_boxes.py:196-216): the goldens of
-    that stage were generated with this same function bound as cv2.minAreaRect, so it is pinned analytically here:
-    the minimum-area rectangle of a rectangle's own corners is that rectangle; of two collinear boxes, their span."""
+    """the product's host `min_area_rect` (post_processor_rotated_boxes.py:196-216 call site), pinned analytically: the
+    minimum-area rectangle of a rectangle's own corners is that rectangle; of two collinear boxes, their span.  (The goldens
+    of the word merge are generated with the INDEPENDENT brute force of oracle/min_area_rect.py bound as cv2.minAreaRect;
+    test_min_area_rect_product_equals_the_independent_oracle below holds the two to each other.)"""
     from glass_amd.postprocess.post_processor_rotated_boxes import min_area_rect
     from known_answers import canonical_rect, rect_points
     g = np.random.default_rng(7)
@@ -236,3 +237,75 @@ def test_min_area_rect_known_answers():
     inner = rect_points(0, 0, 2, 2, 65)
     got = canonical_rect(*min_area_rect(np.concatenate([outer, inner])))
     np.testing.assert_allclose(got, (0, 0, 10, 4, 20), atol=1e-6)
+
+
+def test_min_area_rect_product_equals_the_independent_oracle():
+    """oracle/min_area_rect.py (fp64 brute force over every point pair, no hull, no code shared with the product) against the
+    product's hull walk on 1000 random 8-point sets shaped like the word merge's inputs (the corners of two boxes), on
+    generic point clouds, and on designed ties.  Compared as rectangles (centre, sorted sides, long-side direction mod 180):
+    which of the four (w, h, angle) forms comes back is irrelevant to the caller (reference :266-283 maps all four to one
+    box - checked here too).  Tie-break, documented in the oracle: the first minimal pair in input order; for EQUAL-area
+    rectangles of different shape (a square and the same square turned by 45 degrees) the two implementations may
+    legitimately differ, so those cases assert the AREA only."""
+    from glass_amd.postprocess.post_processor_rotated_boxes import min_area_rect
+    from known_answers import canonical_rect, rect_points
+    from oracle.min_area_rect import min_area_rect_bruteforce
+    g = np.random.default_rng(11)
+    worst = 0.0
+    for k in range(1000):
+        if k % 2 == 0:      # two word boxes: nearly parallel, overlapping or adjacent
+            cx, cy, w, h, a = g.uniform(-200, 200), g.uniform(-200, 200), g.uniform(10, 120), g.uniform(4, 30), g.uniform(-180, 180)
+            p1 = rect_points(cx, cy, w, h, a)
+            t = np.radians(a)
+            p2 = rect_points(cx + np.cos(t) * g.uniform(0.2, 1.2) * w, cy + np.sin(t) * g.uniform(0.2, 1.2) * w + g.uniform(-3, 3),
+                             w * g.uniform(0.5, 1.5), h * g.uniform(0.7, 1.3), a + g.uniform(-8, 8))
+            pts = np.concatenate([p1, p2])
+        else:               # generic clouds of 3..8 points
+            pts = g.uniform(-50, 50, (g.integers(3, 9), 2))
+        pts = pts[g.permutation(len(pts))]
+        want, gap = min_area_rect_bruteforce(pts, return_gap=True)
+        got = min_area_rect(pts)
+        assert abs(got[1][0] * got[1][1] - want[1][0] * want[1][1]) <= 1e-9 * max(1.0, want[1][0] * want[1][1])
+        if gap > 1e-9 * want[1][0] * want[1][1]:            # a unique minimum: the same rectangle
+            a_, b_ = canonical_rect(*got), canonical_rect(*want)
+            if abs(a_[2] - a_[3]) < 1e-9:                   # (a square: its direction is defined mod 90 only)
+                continue
+            d = abs(a_[4] - b_[4])
+            worst = max(worst, float(np.abs(np.array(a_[:4]) - np.array(b_[:4])).max()), min(d, 180.0 - d))
+    assert worst < 1e-7, worst
+    # designed ties: a rectangle's corners given twice; a square + the same square turned by 45 degrees (two different
+    # minimum-area rectangles of equal area: only the area is defined)
+    r = rect_points(3, -2, 40, 10, 17)
+    a_, b_ = canonical_rect(*min_area_rect(np.concatenate([r, r]))), canonical_rect(*min_area_rect_bruteforce(np.concatenate([r, r])))
+    np.testing.assert_allclose(a_, b_, atol=1e-9)
+    sq = np.concatenate([rect_points(0, 0, 10, 10, 0), rect_points(0, 0, 10, 10, 45)])
+    ga, gb = min_area_rect(sq), min_area_rect_bruteforce(sq)
+    assert abs(ga[1][0] * ga[1][1] - gb[1][0] * gb[1][1]) < 1e-9
+
+
+def test_reference_quadrant_logic_is_invariant_to_the_rect_form():
+    """reference post_processor_rotated_boxes.py:264-283: `angle = 90 - angle`, then the orientation decides which of w / h is
+    the width - restated here on the four equivalent (w, h, angle) forms of one rectangle: all give the same rotated box, so
+    the RotatedRect convention of the minAreaRect stand-in cannot leak into the goldens."""
+    def ref_box(center, shape, angle, orientation):
+        angle = 90 - angle
+        diff = (orientation - angle + 180) % 360 - 180
+        if -45 < diff <= 45:
+            width, height = shape[1], shape[0]
+        elif 45 < diff <= 135:
+            width, height = shape[0], shape[1]
+            angle += 90
+        elif -135 < diff <= -45:
+            width, height = shape[0], shape[1]
+            angle -= 90
+        else:
+            width, height = shape[1], shape[0]
+            angle += 180
+        return center[0], center[1], width, height, (angle + 180) % 360 - 180
+    g = np.random.default_rng(3)
+    for _ in range(200):
+        c, w, h, a, o = (g.uniform(0, 100), g.uniform(0, 100)), g.uniform(5, 60), g.uniform(2, 20), g.uniform(-180, 180), g.uniform(-180, 180)
+        forms = [(w, h, a), (h, w, a + 90), (w, h, a + 180), (h, w, a - 90)]
+        boxes = [ref_box(c, (fw, fh), fa, o) for fw, fh, fa in forms]
+        for b in boxes[1:]:
+            np.testing.assert_allclose(b, boxes[0], atol=1e-9)
