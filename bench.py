@@ -276,8 +276,28 @@ def dry_run(args, rank, world, dist) -> None:
         line = {"metric": "DRY RUN of the N-rank plumbing (no GPU, no model): not a measurement", "value": world * B * args.steps / dt,
                 "unit": "synthetic records/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": dt / args.steps * 1e3, "data": "dry-run", "comm": comm}
+        if world > 1:
+            line["cpu_baseline_ref"] = last_cpu_baseline_on_file()
         assert line["n_gpus"] == args.gpus == comm["world_size"]
         print(json.dumps(line), flush=True)
+
+
+def last_cpu_baseline_on_file():
+    """the newest `cpu_baseline` object of an N = 1 line kept in the repository: the driver's BENCH_rNN.json records, else
+    profiles/rNN_bench.json (None when there is none)"""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), reverse=True) + sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")), reverse=True)
+    for path in cands:
+        try:
+            with open(path) as f:
+                js = json.load(f)
+        except (OSError, ValueError):
+            continue
+        js = js.get("parsed", js) if isinstance(js, dict) else {}
+        cb = js.get("cpu_baseline") if isinstance(js, dict) else None
+        if isinstance(cb, dict) and "value" in cb and js.get("n_gpus", 1) == 1:
+            return dict(cb, source=os.path.relpath(path, ROOT))
+    return None
 
 
 def self_launch(args) -> int:
@@ -285,8 +305,11 @@ def self_launch(args) -> int:
     `launch(main, num_gpus, ...)`), each a re-exec of this command with the torch.distributed.run environment, and return
     their exit code.  Refuses - non-zero - when the node cannot give every rank its own GPU (RCCL needs one device per rank);
     GLASS_BENCH_BACKEND=gloo lifts that check to exercise the N-rank plumbing on a 1-GPU box."""
-    from glass_amd.distributed import launch_local_ranks
+    from glass_amd.distributed import launch_local_ranks, preflight_report
     backend = os.environ.get("GLASS_BENCH_BACKEND", "nccl")
+    # first line of a multi-GPU run, before anything can hang: what this node offers (stderr; stdout is the ONE JSON line)
+    print("[bench preflight] " + json.dumps(preflight_report(args.gpus, "gloo" if os.environ.get("GLASS_BENCH_DRYRUN") else backend)),
+          file=sys.stderr, flush=True)
     if os.environ.get("GLASS_BENCH_DRYRUN"):                      # plumbing only: no GPU needed, gloo
         return launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
     if not torch.cuda.is_available():
@@ -320,12 +343,18 @@ def main():
             saved = os.dup(1)
             os.dup2(2, 1)                                         # gloo's connection chatter goes to stderr
             try:
-                dist.init_process_group("gloo")
+                from glass_amd.distributed import init_process_group
+                if os.environ.get("GLASS_BENCH_DRYRUN_ABSENT_RANK") == str(rank):
+                    time.sleep(600)                               # (test hook: a rank that never reaches the rendezvous)
+                init_process_group("gloo")
                 dist.barrier()
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
                 os.close(saved)
+        from glass_amd.distributed import pin_to_gpu_numa_node
+        print(f"[bench rank {rank}] LOCAL_RANK {local_rank} -> (dry run, no device) " + json.dumps(pin_to_gpu_numa_node(local_rank)),
+              file=sys.stderr, flush=True)
         return dry_run(args, rank, world, dist)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -339,16 +368,20 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        from glass_amd.distributed import init_process_group, pin_to_gpu_numa_node
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # per rank, before the model is built: which device this rank drives and which CPUs it was pinned to (its GPU's NUMA node)
+        print(f"[bench rank {rank}] LOCAL_RANK {local_rank} -> cuda:{dev_index} ({torch.cuda.get_device_name(dev_index)}) "
+              + json.dumps(pin_to_gpu_numa_node(dev_index)), file=sys.stderr, flush=True)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            init_process_group("nccl", device=dev)               # 120 s rendezvous / collective timeout: fail fast, not in 10 minutes
         else:
             # gloo's C++ side prints "[Gloo] Rank r is connected ..." to stdout: keep stdout for the ONE JSON line
             sys.stdout.flush()
             saved = os.dup(1)
             os.dup2(2, 1)
             try:
-                dist.init_process_group(backend)
+                init_process_group(backend)
                 dist.barrier()
             finally:
                 sys.stdout.flush()
@@ -683,6 +716,10 @@ def main():
             line["config"]["inputs"] = "uint8 HWC in pinned host memory (--from-host): PCIe-inclusive, NOT the contract's value"
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_side, args.rois)
+        elif world > 1:
+            # the CPU baseline is timed on rank 0 of the N = 1 run only (it needs the host cores to itself); an N > 1 line
+            # carries the most recent N = 1 measurement on file as `cpu_baseline_ref`, named by its source
+            line["cpu_baseline_ref"] = last_cpu_baseline_on_file()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -188,14 +188,19 @@ __global__ __launch_bounds__(256, 1) void backbone_stem_fused_kernel(BStemParams
       // (two ds_read2_b64: this lane's 4 floats for each M-block) are requested before this group's 16 MFMAs
       // (an M-block past the image's right edge reads zero-filled ring pixels: finite values nobody stores)
       auto a_ptr = [&](int g) { return ring + ring_slot(2 * oy - 3 + g / 3) * RS + 4 * (g % 3); };
-      float4 c0 = *reinterpret_cast<const float4*>(a_ptr(0) + a_off0), c1 = *reinterpret_cast<const float4*>(a_ptr(0) + a_off1);
+      // (ring offsets 6 col + 6 + 12 kg + 4 (g % 3) are 8-byte aligned, 16-byte aligned only for odd columns: the access
+      //  type says so - `f4a8` - and the compiler emits ds_read2_b64; a float4 dereference promised an alignment the address
+      //  does not have and a ds_read_b128 off its natural alignment is replayed by the LDS)
+      struct __attribute__((aligned(8))) f4a8 { float x, y, z, w; };
+      auto ld4 = [](const float* q) { const f4a8 v = *reinterpret_cast<const f4a8*>(q); return make_float4(v.x, v.y, v.z, v.w); };
+      float4 c0 = ld4(a_ptr(0) + a_off0), c1 = ld4(a_ptr(0) + a_off1);
       static_for<0, 21>([&](auto g_) {
         constexpr int g = decltype(g_)::value;
         constexpr int ky = g / 3, s0 = 4 * (g % 3);
         float4 n0 = c0, n1 = c1;
         if constexpr (g + 1 < 21) {
-          n0 = *reinterpret_cast<const float4*>(a_ptr(g + 1) + a_off0);
-          n1 = *reinterpret_cast<const float4*>(a_ptr(g + 1) + a_off1);
+          n0 = ld4(a_ptr(g + 1) + a_off0);
+          n1 = ld4(a_ptr(g + 1) + a_off1);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float a0[4] = {c0.x, c0.y, c0.z, c0.w}, a1[4] = {c1.x, c1.y, c1.z, c1.w};

@@ -28,10 +28,12 @@ def load_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
 
 
 def fold_conv(sd: Dict[str, torch.Tensor], conv: str, norm: Optional[str], device, cin_pad: int = 4,
-              eps: float = BN_EPS, stride=1, ragged: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """conv `conv`.weight[/bias] followed by eval-mode BatchNorm `norm`.* -> (w_khwc, bias).  `stride`: the layer's stride
-    when it is not 1 (a strided 3x3 layer gets no Winograd packs); `ragged`: the layer runs on maps of width 4 k + 1 (it gets the
-    last-column strip weights next to its Winograd form, ops.native.conv2d_nhwc)."""
+              eps: float = BN_EPS, ragged: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """conv `conv`.weight[/bias] followed by eval-mode BatchNorm `norm`.* -> (w_khwc, bias).  `ragged`: the layer runs on maps
+    of odd width (the local extractor's 16 x 33): it gets the last-column strip weights next to its Winograd forms
+    (ops.native.conv2d_nhwc).  (Every 3x3 layer of this model has stride 1 - STRIDE_IN_1X1 puts a block's stride on its 1x1
+    conv - so there is no stride to tell the packer about; ops.native.prepare_conv_weights keeps the argument for callers
+    that have one.)"""
     w = sd[conv + ".weight"].double()
     b = sd[conv + ".bias"].double() if (conv + ".bias") in sd else None
     if norm is not None and (norm + ".weight") in sd:
@@ -44,17 +46,17 @@ def fold_conv(sd: Dict[str, torch.Tensor], conv: str, norm: Optional[str], devic
     cin4 = (cin + cin_pad - 1) // cin_pad * cin_pad
     out = torch.zeros((cout, kh, kw, cin4), dtype=torch.float32)
     out[..., :cin] = w.permute(0, 2, 3, 1).float()
-    return conv_weight(out, device, stride, ragged), (None if b is None else b.float().contiguous().to(device))
+    return conv_weight(out, device, ragged), (None if b is None else b.float().contiguous().to(device))
 
 
 def dev(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().float().contiguous().to(device)
 
 
-def conv_weight(w: torch.Tensor, device, stride=1, ragged: bool = False):
+def conv_weight(w: torch.Tensor, device, ragged: bool = False):
     """[Cout,KH,KW,Cin] (conv) or [Nout,K] (linear) -> ops.native.ConvWeight on `device`: the raw fp32 tensor plus every
     packed form the layer's kernels stream (Winograd U, pointwise / fp16 MFMA fragment order), built here, ONCE, for the conv
     routing of the model being loaded (ops.native.packing_for: its precision decides the forms, and the Routing itself is stamped
     on the ConvWeight so that the layer's launches follow it).  CPU `device` (host-only tests): raw tensor only."""
     from .ops import native as K
-    return K.prepare_conv_weights(dev(w, device), stride=stride, ragged=ragged)
+    return K.prepare_conv_weights(dev(w, device), ragged=ragged)

@@ -263,18 +263,22 @@ def launch_local_ranks(argv: Sequence[str], world_size: int, port: Optional[int]
     terminates the remaining ranks (SIGTERM to exactly the process groups started here, SIGKILL after `grace_s`) and is
     returned - a rank that died must not leave the others waiting in a collective.  0 = every rank exited 0.
     The ranks never outlive the launcher: SIGTERM / SIGINT / SIGHUP to the launcher stop them the same way (and return
-    128 + signal), and a launcher that is killed outright takes them along (`_die_with_parent`)."""
+    128 + signal), and a launcher that is killed outright takes them along (`_die_with_parent`).
+    Call it from the MAIN thread: the signal handlers can only be installed there, and Linux delivers PR_SET_PDEATHSIG when
+    the THREAD that forked the rank exits - from a short-lived worker thread the ranks would be killed when that thread
+    returns, so off the main thread the ranks are started without it (and then only the explicit stop paths apply)."""
     import signal
     import threading
     if world_size < 1:
         raise ValueError("world_size must be >= 1")
     port = free_port() if port is None else int(port)
+    on_main = threading.current_thread() is threading.main_thread()
     procs = [subprocess.Popen(list(argv), env=rank_env(r, world_size, port, base_env), start_new_session=True,
-                              preexec_fn=_die_with_parent)
+                              preexec_fn=_die_with_parent if on_main else None)
              for r in range(world_size)]
     rc = 0
     old_handlers = {}
-    if threading.current_thread() is threading.main_thread():
+    if on_main:
         def on_signal(signum, _frame):
             raise _Terminated(signum)
         for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
@@ -299,20 +303,125 @@ def launch_local_ranks(argv: Sequence[str], world_size: int, port: Optional[int]
         rc = 128 + int(e.args[0])
         print(f"[launch_local_ranks] signal {int(e.args[0])}: stopping the ranks", file=sys.stderr)
     finally:
-        for sg, h in old_handlers.items():
-            signal.signal(sg, signal.SIG_IGN)                        # no second interruption while the ranks are being stopped
-        for sig, wait in ((signal.SIGTERM, grace_s), (signal.SIGKILL, grace_s)):
-            left = [p for p in procs if p.poll() is None]
-            if not left:
+        def stop_ranks():
+            for sg in old_handlers:
+                signal.signal(sg, signal.SIG_IGN)                    # no second interruption while the ranks are being stopped
+            for sig, wait in ((signal.SIGTERM, grace_s), (signal.SIGKILL, grace_s)):
+                left = [p for p in procs if p.poll() is None]
+                if not left:
+                    break
+                for p in left:
+                    try:
+                        os.killpg(p.pid, sig)                        # start_new_session: pgid == pid of the rank we started
+                    except ProcessLookupError:
+                        pass
+                t_end = time.time() + wait
+                while time.time() < t_end and any(p.poll() is None for p in left):
+                    time.sleep(poll_s)
+        # a signal that lands after the poll loop but before SIG_IGN is installed raises _Terminated INSIDE this block: the
+        # kill loop must still run (it was skipped, ranks survived a doubly-signalled launcher) - retry until it has
+        while True:
+            try:
+                stop_ranks()
                 break
-            for p in left:
-                try:
-                    os.killpg(p.pid, sig)                            # start_new_session: pgid == pid of the rank we started
-                except ProcessLookupError:
-                    pass
-            t_end = time.time() + wait
-            while time.time() < t_end and any(p.poll() is None for p in left):
-                time.sleep(poll_s)
+            except _Terminated as e:
+                rc = rc or 128 + int(e.args[0])
         for sg, h in old_handlers.items():
             signal.signal(sg, h)
     return rc
+
+
+# ---------------------------------------------------------------------------------------------- first-contact hardening
+# The N-GPU path (RCCL over xGMI) cannot be exercised from the build container (1-GPU leases): the first run is the
+# driver's.  Everything below makes that run fail FAST and LEGIBLY instead of hanging: a rendezvous timeout, a preflight
+# report before any model is built, and each rank pinned to the CPUs of its GPU's NUMA node.
+
+RENDEZVOUS_TIMEOUT_S = 120
+
+
+def init_process_group(backend: str, device: Optional[torch.device] = None, timeout_s: Optional[float] = None):
+    """torch.distributed.init_process_group with a rendezvous / collective timeout of `timeout_s` (default 120 s, or
+    $GLASS_DIST_TIMEOUT_S) instead of torch's 10-30 minutes: a rank that never shows up makes every other rank raise within
+    the timeout and exit non-zero (bench.py's launcher then stops the rest).  Returns the timeout used (seconds)."""
+    import datetime
+    import torch.distributed as dist
+    t = float(os.environ.get("GLASS_DIST_TIMEOUT_S", RENDEZVOUS_TIMEOUT_S) if timeout_s is None else timeout_s)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {"timeout": datetime.timedelta(seconds=t)}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+    return t
+
+
+def gpu_numa_cpus(dev_index: int) -> Tuple[Optional[int], List[int], str]:
+    """(numa node, its CPUs, PCI address) of CUDA/HIP device `dev_index` from sysfs; node None when the platform does not say
+    (single-node hosts report -1) or the device cannot be located."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}.0"
+    except Exception:                                            # noqa: BLE001 - no device: nothing to pin to
+        return None, [], "?"
+    return _numa_cpus_of_pci(bdf) + (bdf,)
+
+
+def _numa_cpus_of_pci(bdf: str, sysfs: str = "/sys") -> Tuple[Optional[int], List[int]]:
+    try:
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None, []
+    if node < 0:
+        return None, []
+    try:
+        return node, parse_cpulist(open(os.path.join(sysfs, "devices/system/node", f"node{node}", "cpulist")).read())
+    except OSError:
+        return node, []
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the sysfs cpulist format)"""
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def pin_to_gpu_numa_node(dev_index: int) -> Dict[str, object]:
+    """Restrict this process to the CPUs of its GPU's NUMA node (intersection with the CPUs it may already use; nothing
+    happens when the node is unknown or the intersection is empty - a pin must never take CPUs away entirely).  Launch glue
+    and pinned-memory copies then stay on the socket the GPU hangs off.  Returns a report for the preflight line."""
+    node, cpus, bdf = gpu_numa_cpus(dev_index)
+    rep: Dict[str, object] = {"device": dev_index, "pci": bdf, "numa_node": node, "pinned": False}
+    try:
+        have = os.sched_getaffinity(0)
+    except AttributeError:                                       # pragma: no cover (non-linux)
+        return rep
+    rep["cpus_before"] = len(have)
+    want = have & set(cpus)
+    if node is not None and want and want != have:
+        try:
+            os.sched_setaffinity(0, want)
+            rep["pinned"] = True
+        except OSError as e:
+            rep["error"] = str(e)
+    rep["cpus_after"] = len(os.sched_getaffinity(0))
+    return rep
+
+
+def preflight_report(world_size: int, backend: str) -> Dict[str, object]:
+    """what a failed multi-GPU run needs on its first line: visible devices, RCCL version, the IPC mode the host driver needs,
+    the rendezvous address - gathered WITHOUT touching a device context or a process group"""
+    rep: Dict[str, object] = {"world_size": world_size, "backend": backend, "cuda_available": bool(torch.cuda.is_available()),
+                              "devices_visible": torch.cuda.device_count() if torch.cuda.is_available() else 0,
+                              "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                              "MASTER_ADDR": os.environ.get("MASTER_ADDR"), "MASTER_PORT": os.environ.get("MASTER_PORT"),
+                              "timeout_s": float(os.environ.get("GLASS_DIST_TIMEOUT_S", RENDEZVOUS_TIMEOUT_S)), "torch": torch.__version__,
+                              "hip": getattr(torch.version, "hip", None)}
+    try:
+        rep["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                                       # noqa: BLE001 - a report field, never fatal
+        rep["rccl_version"] = f"unavailable ({type(e).__name__})"
+    return rep

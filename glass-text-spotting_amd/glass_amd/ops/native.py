@@ -321,7 +321,9 @@ class ConvWeight:
         self.raw = _f32c(raw, "w")
         self.packs = {}
         self.routing = routing
-        self.version = raw._version
+        # (tensors created under torch.inference_mode() carry no version counter: loading a model inside inference_mode()
+        #  must work - such weights cannot be edited in place anyway, so there is no staleness to detect)
+        self.version = None if raw.is_inference() else raw._version
 
     @property
     def shape(self):
@@ -415,7 +417,7 @@ def packs_on_the_fly() -> int:
 
 def _packed(w, wt: torch.Tensor, kind) -> torch.Tensor:
     if isinstance(w, ConvWeight):
-        if w.version != wt._version:
+        if w.version is not None and not wt.is_inference() and w.version != wt._version:
             # `raw` was written in place since it was packed: every pack is stale.  Re-pack the forms the layer had, on this
             # launch's stream (stream order covers this launch; a caller that edits weights while OTHER streams are launching
             # with them has to synchronise itself, as with any tensor)

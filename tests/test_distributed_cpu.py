@@ -351,3 +351,63 @@ def test_ranks_never_outlive_the_launcher(tmp_path):
         while time.time() < t_end and any(_alive(p) for p in pids):
             time.sleep(0.1)
         assert not any(_alive(p) for p in pids), f"ranks survived a launcher that got {how}"
+
+
+# ------------------------------------------------------------------------------------------- first-contact hardening (round 5)
+
+def test_bench_preflight_rank_report_and_baseline_ref_in_the_dry_run():
+    """`GLASS_BENCH_DRYRUN=1 python bench.py --gpus 2` prints, BEFORE any rank can hang: one preflight line (devices visible,
+    RCCL version, HSA_ENABLE_IPC_MODE_LEGACY, timeout) and one line per rank (LOCAL_RANK -> device, NUMA pin report); the N > 1
+    line carries the last N = 1 CPU baseline on file as `cpu_baseline_ref` and no `cpu_baseline` of its own."""
+    import json
+    p = _run_bench({"GLASS_BENCH_DRYRUN": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    pre = [ln for ln in p.stderr.splitlines() if ln.startswith("[bench preflight] ")]
+    assert len(pre) == 1
+    rep = json.loads(pre[0][len("[bench preflight] "):])
+    assert rep["world_size"] == 2 and rep["backend"] == "gloo" and "rccl_version" in rep and "HSA_ENABLE_IPC_MODE_LEGACY" in rep
+    assert rep["timeout_s"] == 120.0 and "devices_visible" in rep
+    ranks = sorted(ln for ln in p.stderr.splitlines() if ln.startswith("[bench rank "))
+    assert len(ranks) == 2 and "LOCAL_RANK 0" in ranks[0] and "LOCAL_RANK 1" in ranks[1] and '"pinned"' in ranks[0]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert "cpu_baseline" not in d
+    ref = d["cpu_baseline_ref"]
+    assert ref is None or (ref["value"] > 0 and ref["source"].endswith(".json") and "cores" in ref)
+    assert os.path.exists(os.path.join(ROOT, "BENCH_r04.json")) and ref is not None      # this repository has one on file
+
+
+def test_a_rank_that_never_joins_makes_every_rank_exit_nonzero_within_the_timeout():
+    """RCCL first contact: a rank that never reaches the rendezvous (hook: it sleeps instead) must not leave the others waiting
+    for torch's default 10-30 minutes - `distributed.init_process_group` uses GLASS_DIST_TIMEOUT_S (120 s by default, 6 s here),
+    the waiting rank raises, the launcher sees a non-zero exit and stops the sleeper; no line is printed."""
+    import time
+    t0 = time.time()
+    p = _run_bench({"GLASS_BENCH_DRYRUN": "1", "GLASS_BENCH_DRYRUN_ABSENT_RANK": "1", "GLASS_DIST_TIMEOUT_S": "6"},
+                   "--gpus", "2", "--steps", "2", "--warmup", "0", timeout=180)
+    dt = time.time() - t0
+    assert p.returncode != 0 and p.stdout.strip() == "", (p.returncode, p.stdout)
+    assert dt < 90, f"took {dt:.0f} s: the rendezvous timeout did not apply"
+    assert "stopping the other ranks" in p.stderr
+
+
+def test_numa_pinning_helpers(tmp_path):
+    """sysfs parsing behind pin_to_gpu_numa_node: cpulist format, a fake /sys tree, the unknown-node (-1) and missing-device
+    cases; without a GPU the pin is a no-op that still reports."""
+    from glass_amd import distributed as D
+    assert D.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and D.parse_cpulist("") == [] and D.parse_cpulist("5") == [5]
+    sysfs = tmp_path / "sys"
+    (sysfs / "bus/pci/devices/0000:0d:00.0").mkdir(parents=True)
+    (sysfs / "bus/pci/devices/0000:0d:00.0/numa_node").write_text("1\n")
+    (sysfs / "bus/pci/devices/0000:1a:00.0").mkdir(parents=True)
+    (sysfs / "bus/pci/devices/0000:1a:00.0/numa_node").write_text("-1\n")
+    (sysfs / "devices/system/node/node1").mkdir(parents=True)
+    (sysfs / "devices/system/node/node1/cpulist").write_text("64-127,192-255\n")
+    node, cpus = D._numa_cpus_of_pci("0000:0d:00.0", str(sysfs))
+    assert node == 1 and len(cpus) == 128 and cpus[0] == 64 and cpus[-1] == 255
+    assert D._numa_cpus_of_pci("0000:1a:00.0", str(sysfs)) == (None, [])
+    assert D._numa_cpus_of_pci("0000:ff:00.0", str(sysfs)) == (None, [])
+    before = os.sched_getaffinity(0)
+    rep = D.pin_to_gpu_numa_node(0)                      # no GPU here: nothing to pin to
+    assert rep["pinned"] is False and os.sched_getaffinity(0) == before and rep["cpus_after"] == len(before)
+    pre = D.preflight_report(8, "nccl")
+    assert pre["world_size"] == 8 and pre["devices_visible"] == 0 and pre["timeout_s"] == 120.0
