@@ -127,3 +127,47 @@ extern "C" int glass_detections_finalize(const float* boxes, const float* scores
   GLASS_CHECK_LAUNCH("glass_detections_finalize");
   return GLASS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- word records
+// The fixed-size per-image record the ranks exchange (glass_amd/distributed.py words_record_size; replaces the reference's
+// pickled comm.gather, glass/evaluation/text_evaluator.py:246-249) straight from the padded outputs of
+// glass_postprocess_words:  [count | boxes 5D | score D | text score D | polygon 8D | text length D | character D*T], all
+// float32, rows beyond min(count, K, D) and steps beyond min(Tw, T) zero.  One launch instead of a fill + eight strided
+// copies and casts.
+__global__ __launch_bounds__(256) void pack_word_records_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                                const float* __restrict__ tscore, const float* __restrict__ polys,
+                                                                const int* __restrict__ tlen, const int* __restrict__ chars,
+                                                                const int* __restrict__ count, int K, int Tw, int D, int T,
+                                                                float* __restrict__ rec) {
+  const int n = blockIdx.x;
+  const int L = 1 + D * (5 + 1 + 1 + 8 + 1 + T);
+  const int c = min(count[n], D);          // what the record says ...
+  const int k = min(K, D);                 // ... and the rows the inputs really hold
+  float* r = rec + (long)n * L;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    float v = 0.f;
+    if (i == 0) v = (float)c;
+    else {
+      int o = i - 1;
+      if (o < 5 * D) { const int d = o / 5; if (d < k) v = boxes[((long)n * K + d) * 5 + o % 5]; }
+      else if ((o -= 5 * D) < D) { if (o < k) v = scores[(long)n * K + o]; }
+      else if ((o -= D) < D) { if (o < k) v = tscore[(long)n * K + o]; }
+      else if ((o -= D) < 8 * D) { const int d = o / 8; if (d < k) v = polys[((long)n * K + d) * 8 + o % 8]; }
+      else if ((o -= 8 * D) < D) { if (o < k) v = (float)tlen[(long)n * K + o]; }
+      else { o -= D; const int d = o / T, t = o % T; if (d < k && t < Tw) v = (float)chars[((long)n * K + d) * Tw + t]; }
+    }
+    r[i] = v;
+  }
+}
+
+extern "C" int glass_pack_word_records(const float* boxes, const float* scores, const float* text_score, const float* polygons,
+                                       const int* text_len, const int* chars, const int* count, int N, int K, int Tw, int max_det,
+                                       int steps, float* records, glass_stream_t stream) {
+  if (N == 0) return GLASS_OK;
+  GLASS_CHECK_ARG(boxes && scores && text_score && polygons && text_len && chars && count && records, "glass_pack_word_records: null pointer");
+  GLASS_CHECK_ARG(K >= 0 && Tw > 0 && max_det > 0 && steps > 0, "glass_pack_word_records: bad sizes");
+  hipLaunchKernelGGL(pack_word_records_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, boxes, scores, text_score, polygons, text_len,
+                     chars, count, K, Tw, max_det, steps, records);
+  GLASS_CHECK_LAUNCH("glass_pack_word_records");
+  return GLASS_OK;
+}

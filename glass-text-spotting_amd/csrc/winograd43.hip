@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
           rres[cb][a * 4 + b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rrow[a] + rcol[b], cb * 64, 0));
     }
   };
+#ifdef GLASS_W43_SPLIT_STORES   // the round-2..4 epilogue (A/B builds only: scripts/build_variant_lib.sh w43old -DGLASS_W43_SPLIT_STORES)
   load_res(ic<0>{});
   static_for<2>([&](auto cb_) {
     constexpr int cb = decltype(cb_)::value;
@@ -343,6 +344,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yrow[a] + ycol[b], cb * 64, 0);
       }
   });
+#else
+  load_res(ic<0>{});
+  // Both channel blocks' outputs are finished BEFORE the first store, and a pixel's two 64-byte halves (cb = 0 | 1: one 128-byte
+  // line) leave in adjacent store instructions.  Storing block 0 right after its transform - a whole output transform (~1 us)
+  // before block 1 - had the L2 write a line back half-filled and again when the other half arrived: PMC WRITE_SIZE was 1.36x
+  // the output tensor on the FPN p2 layer (scripts/exp_write_size.py; a copy, the implicit-GEMM and the pointwise kernel
+  // write 1.00x).  The accumulators are dead by then, so the 128 output registers cost nothing.
+  f32x4 outs[2][16];
+  static_for<2>([&](auto cb_) {
+    constexpr int cb = decltype(cb_)::value;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + cbase + 16 * cb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float z[6][4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        at4(acc[i * 6 + 0][cb][e], acc[i * 6 + 1][cb][e], acc[i * 6 + 2][cb][e], acc[i * 6 + 3][cb][e], acc[i * 6 + 4][cb][e],
+            acc[i * 6 + 5][cb][e], z[i][0], z[i][1], z[i][2], z[i][3]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float y0, y1, y2, y3;
+        at4(z[0][b], z[1][b], z[2][b], z[3][b], z[4][b], z[5][b], y0, y1, y2, y3);
+        outs[cb][0 * 4 + b][e] = y0; outs[cb][1 * 4 + b][e] = y1; outs[cb][2 * 4 + b][e] = y2; outs[cb][3 * 4 + b][e] = y3;
+      }
+    }
+    // the other channel block's residual rows are requested as soon as this block's accumulators are dead, a whole
+    // output transform ahead of their use
+    if constexpr (cb == 0) { __builtin_amdgcn_sched_barrier(0); load_res(ic<1>{}); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int ab = 0; ab < 16; ++ab) {
+      f32x4 v = outs[cb][ab] + bv;
+      v.x = fmaxf(v.x, lo2); v.y = fmaxf(v.y, lo2); v.z = fmaxf(v.z, lo2); v.w = fmaxf(v.w, lo2);
+      if (p.res_mode == 1) v = v + rres[cb][ab];
+      v.x = fmaxf(v.x, lo1); v.y = fmaxf(v.y, lo1); v.z = fmaxf(v.z, lo1); v.w = fmaxf(v.w, lo1);
+      outs[cb][ab] = v;
+    }
+  });
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outs[0][a * 4 + b]), yr, yrow[a] + ycol[b], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outs[1][a * 4 + b]), yr, yrow[a] + ycol[b], 64, 0);
+    }
+#endif
   if constexpr (ABL == 4) {
     __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();

@@ -26,7 +26,7 @@ EXPORTS = [
     "glass_winograd43_supported", "glass_winograd43_weight_floats", "glass_winograd43_pack_weights", "glass_conv3x3_winograd43_nhwc",
     "glass_maxpool2d_nhwc", "glass_maxpool2d_nhwc_h16", "glass_roi_align_rotated_h16", "glass_pixel_shuffle2x_nhwc", "glass_sigmoid_inplace", "glass_paste_rotated_masks", "glass_mul_inplace", "glass_cast_f32_to_f16",
     "glass_preprocess_image", "glass_image_u8hwc_to_chw_resized", "glass_roi_align_rotated",
-    "glass_rpn_workspace_bytes", "glass_rpn_topk_decode", "glass_rotated_nms_select", "glass_pairwise_iou_rotated", "glass_detections_finalize", "glass_postprocess_words", "glass_text_argmax",
+    "glass_rpn_workspace_bytes", "glass_rpn_topk_decode", "glass_rotated_nms_select", "glass_pairwise_iou_rotated", "glass_detections_finalize", "glass_postprocess_words", "glass_text_argmax", "glass_pack_word_records",
     "glass_box_decode", "glass_gc_attention_inplace", "glass_mean_over_h", "glass_bilstm_workspace_bytes", "glass_bilstm_recurrence",
     "glass_bilstm_persistent_workspace_bytes", "glass_bilstm_recurrence_persistent", "glass_recurrence_status",
     "glass_decode_persistent_supported", "glass_decode_persistent_workspace_bytes", "glass_attention_decode_persistent",

@@ -99,10 +99,14 @@ def words_record_size(max_det: int, steps: int) -> int:
 
 def pack_words(words: dict, max_det: int, steps: int) -> torch.Tensor:
     """Record of the POST-PROCESSED words of a step (the padded outputs of ops.native.postprocess_words):
-    [count | boxes 5D | score D | text score D | polygon 8D | text length D | character index D*T]."""
+    [count | boxes 5D | score D | text score D | polygon 8D | text length D | character index D*T].  Device tensors: ONE
+    launch (glass_pack_word_records); host tensors (the CPU tests of the gather plumbing): the same layout with torch."""
     N, K = words["scores"].shape
     dev = words["scores"].device
     D = max_det
+    if dev.type == "cuda":
+        from .ops import native as KN
+        return KN.pack_word_records(words, D, steps)
     k = min(K, D)
     T = min(steps, words["char"].shape[2])
     rec = torch.zeros((N, words_record_size(D, steps)), dtype=torch.float32, device=dev)

@@ -840,6 +840,19 @@ def rpn_topk_decode(levels: Sequence[dict], N: int, A: int, anchor_offset: float
 NMS_CLIP, NMS_DROP_EMPTY = 1, 2
 
 
+def zeros_views(fields, device) -> list:
+    """[(shape, dtype float32 | int32) ...] -> zeroed tensors that are views of ONE flat buffer: one fill launch instead of one
+    per output (padded outputs whose tails the kernels do not write must read zero; every view starts 16-byte aligned)"""
+    sizes = [(int(math.prod(shape)) + 3) // 4 * 4 for shape, _ in fields]
+    flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=device)
+    out, off = [], 0
+    for (shape, dt), n in zip(fields, sizes):
+        v = flat[off:off + int(math.prod(shape))]
+        out.append((v if dt == torch.float32 else v.view(torch.int32)).view(shape))
+        off += n
+    return out
+
+
 def rotated_nms_select(boxes: torch.Tensor, scores: torch.Tensor, cat: Optional[torch.Tensor],
                        valid_count: Optional[torch.Tensor], image_hw: torch.Tensor, score_thresh: float, nms_thresh: float,
                        post_topk: int, flags: int):
@@ -847,10 +860,8 @@ def rotated_nms_select(boxes: torch.Tensor, scores: torch.Tensor, cat: Optional[
     _f32c(boxes, "boxes"); _f32c(scores, "scores"); _i32(image_hw, "image_hw")
     N, S = scores.shape
     dev = boxes.device
-    ob = torch.zeros((N, post_topk, 5), dtype=torch.float32, device=dev)
-    os_ = torch.zeros((N, post_topk), dtype=torch.float32, device=dev)
-    oi = torch.zeros((N, post_topk), dtype=torch.int32, device=dev)
-    oc = torch.zeros((N,), dtype=torch.int32, device=dev)
+    ob, os_, oi, oc = zeros_views([((N, post_topk, 5), torch.float32), ((N, post_topk), torch.float32), ((N, post_topk), torch.int32),
+                                   ((N,), torch.int32)], dev)
     check(lib().glass_rotated_nms_select(
         c_void_p(_dev(boxes)), c_void_p(_dev(scores)), c_void_p(_dev(_i32(cat, "cat")) if cat is not None else None),
         c_void_p(_dev(_i32(valid_count, "valid_count")) if valid_count is not None else None), N, S,
@@ -1017,12 +1028,13 @@ def detections_finalize(boxes: torch.Tensor, scores: torch.Tensor, orient: Optio
     """Batched meta-arch postprocess. boxes [N,K,5] ... -> (boxes, scores, orient|None, text|None, counts) padded."""
     N, K, _ = boxes.shape
     dev = boxes.device
-    ob = torch.zeros((N, K, 5), dtype=torch.float32, device=dev)
-    os_ = torch.zeros((N, K), dtype=torch.float32, device=dev)
-    oo = torch.zeros((N, K, 2), dtype=torch.float32, device=dev) if orient is not None else None
     TC = int(text.shape[1] * text.shape[2]) if text is not None else 0
-    ot = torch.zeros((N, K) + tuple(text.shape[1:]), dtype=torch.float32, device=dev) if text is not None else None
-    oc = torch.zeros((N,), dtype=torch.int32, device=dev)
+    ob, os_, oo, ot, oc = zeros_views([((N, K, 5), torch.float32), ((N, K), torch.float32),
+                                       ((N, K, 2) if orient is not None else (0,), torch.float32),
+                                       ((N, K) + tuple(text.shape[1:]) if text is not None else (0,), torch.float32),
+                                       ((N,), torch.int32)], dev)
+    oo = oo if orient is not None else None
+    ot = ot if text is not None else None
     _f32c(boxes, "boxes"); _f32c(scores, "scores"); _i32(counts, "counts"); _f32c(scale_xy, "scale_xy"); _i32(out_hw, "out_hw")
     opt = lambda t: c_void_p(_dev(t)) if t is not None else c_void_p(None)
     check(lib().glass_detections_finalize(
@@ -1043,6 +1055,19 @@ def text_argmax(text: torch.Tensor, counts: torch.Tensor):
     check(lib().glass_text_argmax(c_void_p(_dev(text)), c_void_p(_dev(counts)), N, K, T, C, c_void_p(_dev(arg)), c_void_p(_dev(mx)),
                                   c_void_p(stream_handle())), "glass_text_argmax")
     return arg, mx
+
+
+def pack_word_records(words: dict, max_det: int, steps: int) -> torch.Tensor:
+    """the padded outputs of postprocess_words -> [N, 1 + max_det (16 + steps)] float32 word records (one launch)"""
+    N, Kk = words["scores"].shape
+    Tw = int(words["char"].shape[2])
+    rec = torch.empty((N, 1 + max_det * (16 + steps)), dtype=torch.float32, device=words["scores"].device)
+    check(lib().glass_pack_word_records(c_void_p(_dev(_f32c(words["boxes"], "boxes"))), c_void_p(_dev(_f32c(words["scores"], "scores"))),
+                                        c_void_p(_dev(_f32c(words["text_score"], "text_score"))), c_void_p(_dev(_f32c(words["polygons"], "polygons"))),
+                                        c_void_p(_dev(_i32(words["text_len"], "text_len"))), c_void_p(_dev(_i32(words["char"], "char"))),
+                                        c_void_p(_dev(_i32(words["count"], "count"))), N, Kk, Tw, int(max_det), int(steps),
+                                        c_void_p(_dev(rec)), c_void_p(stream_handle())), "glass_pack_word_records")
+    return rec
 
 
 def postprocess_words(boxes: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor, text: Optional[torch.Tensor],

@@ -328,6 +328,14 @@ int glass_postprocess_words(const float* boxes, const float* scores, const int* 
  * out_max [N,K,T] the maximum; rows of boxes k >= counts[n] are skipped (outputs untouched).  One wavefront per row.  */
 int glass_text_argmax(const float* text, const int* counts, int N, int K, int T, int C, int* out_arg, float* out_max,
                       glass_stream_t stream);
+/* The fixed-size per-image WORD record the ranks exchange with one all_gather per step (glass_amd/distributed.py; replaces
+ * the reference's pickled comm.gather of per-image results, glass/evaluation/text_evaluator.py:246-249), packed in one launch
+ * from the padded outputs of glass_postprocess_words: records [N, 1 + max_det (16 + steps)] float32 =
+ * [count | boxes 5D | score D | text score D | polygon 8D | text length D | character index D x steps]; rows beyond
+ * min(count, K, max_det) and steps beyond min(Tw, steps) are zero.  chars [N,K,Tw], polygons [N,K,4,2].                    */
+int glass_pack_word_records(const float* boxes, const float* scores, const float* text_score, const float* polygons,
+                            const int* text_len, const int* chars, const int* count, int N, int K, int Tw, int max_det, int steps,
+                            float* records, glass_stream_t stream);
 
 /* pairwise rotated IoU matrix out[n1][n2] (d2 pairwise_iou_rotated; glass/structures/boxes.py:33,
  * used by the post-processor's pairwise_ioa_rotated).                                     */

@@ -430,3 +430,22 @@ def test_pipelined_steps_equal_sequential_steps():
     for (tp_a, bx_a), (tp_b, bx_b) in zip(seq, pip):
         for a, b in zip(tp_a + bx_a, tp_b + bx_b):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,K,Tw,D,T", [(8, 100, 26, 100, 26), (3, 40, 26, 100, 26), (2, 128, 51, 100, 26), (1, 7, 5, 4, 9)])
+def test_pack_word_records_kernel_equals_the_torch_layout(N, K, Tw, D, T):
+    """glass_pack_word_records (one launch) builds exactly the record distributed.pack_words builds with torch slice copies on
+    host tensors - ragged counts, K above and below max_det, fewer and more decoding steps than the record holds."""
+    from glass_amd import distributed as Dm
+    g = torch.Generator().manual_seed(N * 1000 + K)
+    words = {"boxes": torch.randn((N, K, 5), generator=g), "scores": torch.rand((N, K), generator=g),
+             "text_score": torch.rand((N, K), generator=g), "polygons": torch.randn((N, K, 4, 2), generator=g),
+             "text_len": torch.randint(0, Tw + 1, (N, K), generator=g, dtype=torch.int32),
+             "char": torch.randint(0, 97, (N, K, Tw), generator=g, dtype=torch.int32),
+             "count": torch.randint(0, K + 1, (N,), generator=g, dtype=torch.int32)}
+    want = Dm.pack_words(words, D, T)                                    # host tensors: the torch path
+    got = Dm.pack_words({k: v.cuda() for k, v in words.items()}, D, T)    # device tensors: the kernel
+    assert got.is_cuda and tuple(got.shape) == tuple(want.shape) == (N, Dm.words_record_size(D, T))
+    # (the torch path copies every padded row it is given; the kernel too - rows beyond `count` hold whatever the
+    #  post-processor left there, zeros in production)
+    assert torch.equal(got.cpu(), want)
