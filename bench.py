@@ -746,6 +746,10 @@ def main():
         }
         line.update(extras)
         line["lib_source_sha16"] = source_sha16()
+        # the persistent recurrent kernels' in-kernel waits are bounded: a hand-off that gave up raises a sticky status word
+        # (bit 0 BiLSTM, bit 1 decoder) instead of hanging the GPU - 0 over the whole run or the line is not printed
+        line["recurrent_handoff_status"] = K.recurrence_status()
+        assert line["recurrent_handoff_status"] == 0, "a persistent recurrent kernel gave up a hand-off: outputs of that step are garbage"
         # weights are packed in load_state_dict (ops.native.ConvWeight); a launch that had to pack at launch time would
         # mean a layer / precision the loader did not foresee - 0 on this workload
         line["conv_launches_that_packed_weights_at_launch"] = K.packs_on_the_fly()
