@@ -91,11 +91,8 @@ __global__ __launch_bounds__(256) void gc_attention_kernel(float* __restrict__ x
     for (int i = 0; i < GC_U1; ++i) {
       float sa = a[i].x * wm.x + a[i].y * wm.y + a[i].z * wm.z + a[i].w * wm.w;
       float sb = b[i].x * wm.x + b[i].y * wm.y + b[i].z * wm.z + b[i].w * wm.w;
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) {
-        sa += __shfl_xor(sa, off);
-        sb += __shfl_xor(sb, off);
-      }
+      sa = row16_sum(sa);
+      sb = row16_sum(sb);
       if ((lane & 15) == 0) {
         prob[lane >> 4][pos0 + 4 * i] = sa + bm;
         prob[4 + (lane >> 4)][pos0 + 4 * i] = sb + bm;
@@ -425,12 +422,7 @@ __global__ __launch_bounds__(256) void dec_fc_att_kernel(DecParams p, const floa
           if (pr > best) { best = pr; besti = cidx; }
         }
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_xor(best, off);
-        const int oi = __shfl_xor(besti, off);
-        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-      }
+      wave_argmax_first(best, besti);
       if (lane == 0) {
         ycur[r] = besti;
         p.yprev[r0 + r] = besti;

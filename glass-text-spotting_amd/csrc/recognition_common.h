@@ -5,15 +5,59 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+// Wavefront reductions on DPP (data-parallel primitives: the cross-lane operand path of the vector ALU, ~8 cycles per step)
+// instead of __shfl_xor (ds_bpermute_b32: an LDS-crossbar round trip, ~100 cycles per dependent step - the 24 dependent
+// shuffles of a soft-max + arg-max were 2.4 K cycles of the persistent decoder's step).  gfx9 DPP controls: quad_perm,
+// row_half_mirror (0x141), row_mirror (0x140) leave every lane of a 16-lane row with the row's result; row_bcast15 (0x142,
+// rows 1 and 3) and row_bcast31 (0x143, rows 2 and 3) carry it on so that lane 63 holds the wavefront's, read with readlane.
+// `old` is the operation's identity: lanes a row_mask disables get it.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_move(float v, float identity) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum / max over each aligned group of 16 lanes, result in every lane of the group
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v, 0.f);      // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v, 0.f);      // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v, 0.f);     // row_half_mirror
+  v += dpp_move<0x140>(v, 0.f);     // row_mirror
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_move<0xB1>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x4E>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x141>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x140>(v, -INFINITY));
   return v;
+}
+// over the whole wavefront, result wavefront-uniform
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += dpp_move<0x142, 0xa>(v, 0.f);
+  v += dpp_move<0x143, 0xc>(v, 0.f);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  v = fmaxf(v, dpp_move<0x142, 0xa>(v, -INFINITY));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(v, -INFINITY));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// arg-max with the FIRST maximum winning (torch.max semantics): (value, index) per lane -> the wavefront's, uniform
+__device__ __forceinline__ void wave_argmax_first(float& best, int& besti) {
+  const float m = wave_max(best);
+  // lanes that hold the maximum offer their index, the others INT_MAX; the minimum index wins
+  int cand = best == m ? besti : 0x7fffffff;
+  // min over the wavefront as -max(-x) on floats would lose bits: 32-bit integer min on DPP
+  auto imin = [](int a, int b) { return a < b ? a : b; };
+  cand = imin(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0xB1, 0xf, 0xf, false));
+  cand = imin(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x4E, 0xf, 0xf, false));
+  cand = imin(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x141, 0xf, 0xf, false));
+  cand = imin(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x140, 0xf, 0xf, false));
+  cand = imin(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x142, 0xa, 0xf, false));
+  cand = imin(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x143, 0xc, 0xf, false));
+  besti = __builtin_amdgcn_readlane(cand, 63);
+  best = m;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 // tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp/rcp (|err| < 2e-7 absolute; saturates cleanly)

@@ -283,16 +283,18 @@ extern "C" int glass_bilstm_recurrence_persistent(const float* xg, const float* 
 //   * rows [16 j, 16 j + 16) of every matrix that multiplies a vector of ALL 16 RoIs - the three GRU gates (W_hh and the
 //     context half W_ih[:, D:2D]) and sEmbed - as v_mfma_f32_16x16x4_f32 A fragments in registers, cut into K-quarters
 //     (wavefronts 4-7: W_hh and sEmbed, which need h_i only; wavefronts 0-3: the context half);
-//   * the attention, the classifier and the outputs of RoI j of the group: its x and xEmbed(x) rows in LDS (2 x 32 KB,
-//     step-invariant), fc streamed from L2 (97 KB per step, by wavefronts 0-3 while 4-7 run their MFMAs).
+//   * rows [8 j, 8 j + 8) of the classifier fc the same way (wavefronts 0-3, under the others' W_hh / sEmbed products);
+//   * the attention, the soft-max / arg-max and the outputs of RoI j of the group: its x and xEmbed(x) rows in LDS (2 x 32 KB,
+//     step-invariant).  (A first form streamed the whole 97 KB of fc from L2 per workgroup and step: 5.8 K of 25 K cycles.)
 // The embedding half of the GRU input needs no arithmetic at run time: W_ih[:, :D] emb[y] + b_ih is a [C, 3D] table
 // (`emb_gi`, built once at load), gathered by the arg-max.
 // Three hand-offs per step inside the set, all as 8-byte {step tag, value} granules (Guideline 16 R2), double-buffered by
-// step parity like the BiLSTM's: h_i (16 x 256 per consumer, from the owners of its unit slices), sEmbed(h_i) (256 per
-// consumer: a RoI's row from the 16 row owners) and ctx_i + arg-max (16 x 257, from the owners of the RoIs).  Step i:
-//   sweep h_i | W_hh h_i, sEmbed(h_i) (wavefronts 4-7) + fc(h_i[j]) partials (0-3) | publish sEmbed slice; soft-max / arg-max
-//   of step i-1's output (wavefront 4) | sweep sEmbed of RoI j | energies, soft-max, context | publish ctx_j |
-//   sweep ctx, y | W_ih[:, D:] ctx (wavefronts 0-3) | gates -> h_{i+1} slice, publish.
+// step parity like the BiLSTM's: h_i (16 x 256 per consumer, from the owners of its unit slices), sEmbed(h_i) + fc(h_i)
+// (256 + C per consumer: a RoI's rows from the 16 row owners) and ctx_i + arg-max (16 x 257, from the owners of the RoIs).
+// Step i:  sweep h_i | sEmbed(h_i) (wavefronts 4-7) + fc slice (0-3) for the 16 RoIs | publish both slices | W_hh h_i
+//   (wavefronts 4-7, in the shadow of the hand-off); sweep sEmbed of RoI j (wavefronts 0-3); its logits -> soft-max /
+//   arg-max / output row of step i-1 (wavefront 4) |
+//   energies, soft-max, context | publish ctx_j | sweep ctx, y | W_ih[:, D:] ctx (wavefronts 0-3) | gates -> h_{i+1} slice.
 // (A first form kept sEmbed's whole 256 x 256 matrix in 128 registers per thread and skipped the second hand-off: 44
 //  registers spilled to scratch and every phase paid for it - 32 K cycles per step.)
 // Start tickets, bounded spins and the status word are the BiLSTM kernel's (bit 1 of the status word).
@@ -301,6 +303,7 @@ namespace {
 constexpr int PD_D = 256, PD_RB = 16, PD_UB = 16, PD_NS = PD_D / PD_UB;   // hidden size, RoIs per group, rows / workgroups per set
 constexpr int PD_T = 32, PD_CMAX = 128, PD_THREADS = 512;
 constexpr int PD_GRAN = PD_RB * PD_D;
+constexpr int PD_CS = PD_CMAX / PD_NS;   // classes per workgroup of the distributed classifier (8: 16 x 8 >= C)
 
 struct PdParams {
   const float *x, *xproj;
@@ -308,7 +311,7 @@ struct PdParams {
   float temperature;
   int R, T, C, max_len, nsets;
   float* out; int* pred;
-  unsigned long long *hgran, *cgran, *sgran, *ygran;   // per set: [parity][16 x 256] x 3, [parity][16]
+  unsigned long long *hgran, *cgran, *sgran, *ygran, *lgran;   // per set: [parity][16 x 256] x 3, [parity][16], [parity][16 x 128]
   unsigned* ctrl; int* status;
 };
 
@@ -342,7 +345,8 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
   __shared__ float energy[PD_T];
   __shared__ float alpha[PD_THREADS / 64][PD_T];                            // per wavefront: its own copy of the attention weights
   __shared__ float ctxp[2][PD_D];
-  __shared__ float logitp[2][PD_CMAX];
+  __shared__ float lpart[4][PD_RB][PD_UB];                                  // fc: [K-quarter][RoI][class of this workgroup's slice]
+  __shared__ float fcbs[PD_CMAX];                                           // fc bias
   __shared__ unsigned s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_ticket = atomicAdd(p.ctrl, 1u);
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
   gu64* const cg = (gu64*)p.cgran + (long)set * 2 * PD_GRAN;
   gu64* const sg = (gu64*)p.sgran + (long)set * 2 * PD_GRAN;
   gu64* const yg = (gu64*)p.ygran + (long)set * 2 * PD_RB;
+  gu64* const lg = (gu64*)p.lgran + (long)set * 2 * PD_RB * PD_CMAX;
 
   // ---- resident operands: wavefront w = (part = w >> 2: 0 the context half W_ih[:, D:2D], 1 W_hh + sEmbed; K-quarter w & 3)
   const int part = wave >> 2, kq = wave & 3;
@@ -371,9 +376,14 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
         ga[g][S] = *reinterpret_cast<const float4*>(Wp + (long)(g * PD_D + j * PD_UB + (lane & 15)) * ld + koff + 16 * S);
         asm volatile("" : "+v"(ga[g][S].x), "+v"(ga[g][S].y), "+v"(ga[g][S].z), "+v"(ga[g][S].w));
       }
+    // the fourth row block: sEmbed's rows [16 j, 16 j + 16) on wavefronts 4-7; on wavefronts 0-3 the classifier's rows of THIS
+    // workgroup's class slice [PD_CS j, PD_CS j + PD_CS) (rows beyond the slice or beyond C are zero) - fc is k-blocked [D/4][C][4]
+    const int crow = j * PD_CS + (lane & 15);
+    const bool crow_ok = (lane & 15) < PD_CS && crow < C;
 #pragma unroll
     for (int S = 0; S < 4; ++S) {
-      sa[S] = *reinterpret_cast<const float4*>(p.sW + (long)(j * PD_UB + (lane & 15)) * PD_D + koff + 16 * S);
+      if (part == 1) sa[S] = *reinterpret_cast<const float4*>(p.sW + (long)(j * PD_UB + (lane & 15)) * PD_D + koff + 16 * S);
+      else sa[S] = crow_ok ? reinterpret_cast<const float4*>(p.fcW)[(long)(16 * kq + 4 * S + (lane >> 4)) * C + crow] : make_float4(0.f, 0.f, 0.f, 0.f);
       asm volatile("" : "+v"(sa[S].x), "+v"(sa[S].y), "+v"(sa[S].z), "+v"(sa[S].w));
     }
   }
@@ -390,6 +400,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
   }
   for (int i = tid; i < PD_RB * (PD_D + 4); i += PD_THREADS) (&hs[0][0])[i] = 0.f;        // h_0 = 0
   if (tid < PD_D) wws[tid] = p.wW[tid];
+  if (tid < PD_CMAX) fcbs[tid] = tid < p.C ? p.fcB[tid] : 0.f;
   // element (RoI row pr, row / unit pu of this workgroup's 16) of the threads that finish the row-owner products
   const int pr = (tid >> 4) & 15, pu = tid & 15, u = j * PD_UB + pu;
   const float bh0 = p.b_hh[u], bh1 = p.b_hh[PD_D + u], bh2 = p.b_hh[2 * PD_D + u], sbias = p.sB[u];
@@ -418,73 +429,90 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
     //         wavefronts 0-3: classifier partial sums on h_i of this RoI (= the output of step i - 1)
     if (part == 1) {
       if (i < L) {
+        const f32x4 acc = quarter_job(sa, hs, kq, lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) spart[kq][lane & 15][(lane >> 4) * 4 + e] = acc[e];
+      }
+    } else if (i > 0) {
+      // classifier on h_i (= the output of step i - 1): this workgroup's class slice for all 16 RoIs, one K-quarter per wavefront
+      const f32x4 acc = quarter_job(sa, hs, kq, lane);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lpart[kq][lane & 15][(lane >> 4) * 4 + e] = acc[e];
+    }
+    lds_barrier();
+    PD_STAMP(1)
+    // ---- publish this workgroup's rows of sEmbed(h_i) and its class slice of fc(h_i) for the 16 RoIs (threads 0-255)
+    if (tid < PD_RB * PD_UB) {
+      if (i < L) {
+        const float sv = ((spart[0][pr][pu] + spart[1][pr][pu]) + (spart[2][pr][pu] + spart[3][pr][pu])) + sbias;
+        __hip_atomic_store(sg + (i & 1) * PD_GRAN + pr * PD_D + u, granule((unsigned)(i + 1), sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (i > 0 && pu < PD_CS && j * PD_CS + pu < C) {
+        const float lv = (lpart[0][pr][pu] + lpart[1][pr][pu]) + (lpart[2][pr][pu] + lpart[3][pr][pu]);
+        __hip_atomic_store(lg + ((i & 1) * PD_RB + pr) * PD_CMAX + j * PD_CS + pu, granule((unsigned)(i + 1), lv), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // ---- C: sEmbed(h_i) of THIS RoI, one row from each of the 16 row owners (one granule per thread)
+      if (i < L) {
+        const gu64* src = sg + (i & 1) * PD_GRAN + j * PD_D + tid;
+        unsigned spins = 0;
+        unsigned long long sv;
+        for (;;) {
+          sv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all((unsigned)(sv >> 32) == (unsigned)(i + 1)) || dead) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > PL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(p.status, 2); }
+        }
+        sproj[tid] = __uint_as_float((unsigned)sv);
+      }
+    } else {
+      // ---- wavefronts 4-7: W_hh h_i (needed by the cell update at the end of the step only) in the shadow of the hand-off
+      if (i < L) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
           const f32x4 acc = quarter_job(ga[g], hs, kq, lane);
 #pragma unroll
           for (int e = 0; e < 4; ++e) gpart[1][kq][g][lane & 15][(lane >> 4) * 4 + e] = acc[e];
         }
-        const f32x4 acc = quarter_job(sa, hs, kq, lane);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) spart[kq][lane & 15][(lane >> 4) * 4 + e] = acc[e];
       }
-    } else if (i > 0) {
-      const int c = tid & 127, q = tid >> 7;        // class, K half
-      float acc = 0.f;
-      if (c < C) {
-#pragma unroll 1
-        for (int b = 0; b < 4; ++b) {
-          float4 w8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w8[e] = reinterpret_cast<const float4*>(p.fcW)[(long)(32 * q + 8 * b + e) * C + c];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float4 hv = *reinterpret_cast<const float4*>(&hs[j][4 * (32 * q + 8 * b + e)]);
-            acc += w8[e].x * hv.x + w8[e].y * hv.y + w8[e].z * hv.z + w8[e].w * hv.w;
-          }
-        }
-      }
-      logitp[q][c] = acc;
     }
-    lds_barrier();
-    PD_STAMP(1)
-    // ---- publish this workgroup's rows of sEmbed(h_i) (threads 0-255); wavefront 4: soft-max / arg-max of step i - 1
-    if (tid < PD_RB * PD_UB) {
-      if (i < L) {
-        const float sv = ((spart[0][pr][pu] + spart[1][pr][pu]) + (spart[2][pr][pu] + spart[3][pr][pu])) + sbias;
-        __hip_atomic_store(sg + (i & 1) * PD_GRAN + pr * PD_D + u, granule((unsigned)(i + 1), sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    } else if (wave == 4) {
+    if (wave == 4) {
+      // ---- wavefront 4: the logits of THIS RoI from the 16 class-slice owners -> soft-max, arg-max, output row of step i - 1
       if (i > 0) {
         float vv[2], m = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int c = lane + 64 * e;
-          vv[e] = c < C ? (p.fcB[c] + (logitp[0][c] + logitp[1][c])) * p.temperature : -INFINITY;
-          m = fmaxf(m, vv[e]);
+        {
+          const gu64* src = lg + ((i & 1) * PD_RB + j) * PD_CMAX;
+          unsigned spins = 0;
+          unsigned long long l0, l1;
+          for (;;) {
+            l0 = __hip_atomic_load(src + min(lane, C - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l1 = __hip_atomic_load(src + min(lane + 64, C - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(l0 >> 32) == (unsigned)(i + 1) && (unsigned)(l1 >> 32) == (unsigned)(i + 1)) || dead) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(p.status, 2); }
+          }
+          vv[0] = lane < C ? (fcbs[lane] + __uint_as_float((unsigned)l0)) * p.temperature : -INFINITY;
+          vv[1] = lane + 64 < C ? (fcbs[lane + 64] + __uint_as_float((unsigned)l1)) * p.temperature : -INFINITY;
+          m = fmaxf(vv[0], vv[1]);
         }
         m = wave_max(m);
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) { vv[e] = (lane + 64 * e) < C ? expf(vv[e] - m) : 0.f; s += vv[e]; }
+        for (int e = 0; e < 2; ++e) { vv[e] = (lane + 64 * e) < C ? __expf(vv[e] - m) : 0.f; s += vv[e]; }
         s = wave_sum(s);
+        const float inv = 1.f / s;
         float best = -1.f;
         int besti = 0x7fffffff;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int c = lane + 64 * e;
           if (c < C) {
-            const float pv = vv[e] / s;
+            const float pv = vv[e] * inv;
             if (roi_ok) p.out[((long)rr * L + (i - 1)) * C + c] = pv;
             if (pv > best) { best = pv; besti = c; }
           }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          const float ob = __shfl_xor(best, off);
-          const int oi = __shfl_xor(besti, off);
-          if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-        }
+        wave_argmax_first(best, besti);
         if (lane == 0) {
           if (roi_ok) p.pred[(long)rr * L + (i - 1)] = besti;
           // the symbol of step i - 1 feeds step i: tagged i + 1 like the context it is consumed with
@@ -496,19 +524,6 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
       }
     }
     if (i == L) break;
-    // ---- C: sEmbed(h_i) of THIS RoI, one row from each of the 16 row owners (threads 0-255: one granule each)
-    if (tid < PD_D) {
-      const gu64* src = sg + (i & 1) * PD_GRAN + j * PD_D + tid;
-      unsigned spins = 0;
-      unsigned long long sv;
-      for (;;) {
-        sv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all((unsigned)(sv >> 32) == (unsigned)(i + 1)) || dead) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > PL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(p.status, 2); }
-      }
-      sproj[tid] = __uint_as_float((unsigned)sv);
-    }
     lds_barrier();
     PD_STAMP(2)
     //      energies e[t] = wEmbed(tanh(sProj + xProj[t])): thread (t = tid >> 4, 16 channels 4 dq + 64 m), 16 lanes per t
@@ -522,8 +537,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
         const float4 wq = *reinterpret_cast<const float4*>(&wws[64 * m + 4 * dq]);
         s += wq.x * tanh_fast(sp.x + xp.x) + wq.y * tanh_fast(sp.y + xp.y) + wq.z * tanh_fast(sp.z + xp.z) + wq.w * tanh_fast(sp.w + xp.w);
       }
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      s = row16_sum(s);
       if (dq == 0) energy[t] = s + wbias;
     }
     lds_barrier();
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
     {
       const float v = lane < T ? energy[lane & (PD_T - 1)] : -INFINITY;
       const float m = wave_max(v);
-      const float e = lane < T ? expf(v - m) : 0.f;
+      const float e = lane < T ? __expf(v - m) : 0.f;
       const float s = wave_sum(e);
       if (lane < PD_T) alpha[wave][lane] = e / s;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -613,7 +627,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
 
 extern "C" int64_t glass_decode_persistent_workspace_bytes(int R) {
   const int64_t sets = cdiv(R, PD_RB);
-  return (int64_t)PL_CTRL_BYTES + sets * (3 * 2 * PD_GRAN + 2 * PD_RB) * (int64_t)sizeof(unsigned long long);
+  return (int64_t)PL_CTRL_BYTES + sets * (3 * 2 * PD_GRAN + 2 * PD_RB + 2 * PD_RB * PD_CMAX) * (int64_t)sizeof(unsigned long long);
 }
 
 extern "C" int glass_decode_persistent_supported(int T, int D, int C, int max_len) {
@@ -642,6 +656,7 @@ extern "C" int glass_attention_decode_persistent(const float* x, const float* xp
   p.cgran = p.hgran + (size_t)p.nsets * 2 * PD_GRAN;
   p.sgran = p.cgran + (size_t)p.nsets * 2 * PD_GRAN;
   p.ygran = p.sgran + (size_t)p.nsets * 2 * PD_GRAN;
+  p.lgran = p.ygran + (size_t)p.nsets * 2 * PD_RB;
   p.status = recurrence_status_word();
   if (!p.status) { glass_set_error("glass_attention_decode_persistent: no status word (hipMalloc failed)"); return GLASS_EHIP; }
   hipError_t e = hipMemsetAsync(workspace, 0, (size_t)glass_decode_persistent_workspace_bytes(R), s);

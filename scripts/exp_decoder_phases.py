@@ -14,8 +14,8 @@ cfg = get_glass_cfg(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..
 dec = ASTER_V2(cfg, ShapeSpec(channels=256))
 dec.import_weights(make_state_dict(1234), dev, "roi_heads.recognizer_head.decoder.")
 L = lib()
-names = ["A sweep h_i + barrier", "B W_hh h, sEmbed(h) MFMAs (wavefronts 4-7) | fc partials from L2 (0-3) + barrier",
-         "publish sEmbed rows | soft-max / arg-max / out row (wavefront 4); C wait for this RoI's sEmbed row + barrier",
+names = ["A sweep h_i + barrier", "B W_hh h, sEmbed(h) MFMAs (wavefronts 4-7) | fc class slice MFMAs (0-3) + barrier",
+         "publish sEmbed + fc slices; C wait for this RoI's sEmbed row (0-3) | its logits -> soft-max / arg-max / out row (4) + barrier",
          "C energies (tanh) + barrier", "C soft-max + context + barrier", "publish ctx; E wait for the group's contexts",
          "E symbols + embedding rows + barrier", "F context-half MFMAs (wavefronts 0-3) + barrier", "F cell update, publish h"]
 for R in (32, 256):
