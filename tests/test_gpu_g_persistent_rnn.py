@@ -136,3 +136,41 @@ def test_persistent_decoder_under_uneven_load():
         bad += int(not torch.equal(got, ref))          # the same kernel on the same inputs: bit-identical whatever the timing
     torch.cuda.synchronize()
     assert bad == 0 and K.recurrence_status() == 0
+
+
+@pytest.mark.parametrize("T,R", [(20, 24), (7, 5)])
+def test_persistent_decoder_with_fewer_than_32_time_steps(T, R):
+    """T < 32 encoder positions (narrower crops): the step-invariant rows beyond T are zero-filled in LDS and masked out of the
+    attention soft-max - the persistent kernel against the step kernels."""
+    import numpy as np
+    from glass_amd.ops import native as K
+    dec, _ = _decoder()
+    g = torch.Generator().manual_seed(T * 100 + R)
+    x = torch.randn((R, T, 256), generator=g).to(_dev())
+    ri = torch.zeros((R,), dtype=torch.int32, device=_dev())
+    xproj = K.linear(x.view(R * T, 256), dec.w["xW"], dec.w["xB"]).view(R, T, 256)
+    ref = K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode="steps").cpu().numpy()
+    got = K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode=(1, 1)).cpu().numpy()
+    assert K.recurrence_status() == 0
+    srt = np.sort(ref, axis=-1)
+    near_tie = (srt[..., -1] - srt[..., -2]) < 1e-5
+    live = ref.sum(-1) > 0
+    first_tie = np.where((near_tie & live).any(1), (near_tie & live).argmax(1), 26)
+    mask = np.arange(26)[None, :] <= first_tie[:, None]
+    assert float(np.abs(got - ref)[mask].max()) < 1e-5
+
+
+def test_decoder_shapes_the_persistent_kernel_does_not_take_run_the_step_kernels():
+    """T > 32 or C > 128 are outside the persistent kernel's envelope (LDS rows, class slices): the wrapper must fall back to the
+    step kernels, not fail and not produce garbage"""
+    from glass_amd._lib import lib
+    assert lib().glass_decode_persistent_supported(32, 256, 97, 26) == 1
+    assert lib().glass_decode_persistent_supported(40, 256, 97, 26) == 0 and lib().glass_decode_persistent_supported(32, 256, 200, 26) == 0
+    from glass_amd.ops import native as K
+    dec, _ = _decoder()
+    x = torch.randn((6, 40, 256), generator=torch.Generator().manual_seed(5)).to(_dev())
+    ri = torch.zeros((6,), dtype=torch.int32, device=_dev())
+    xproj = K.linear(x.view(6 * 40, 256), dec.w["xW"], dec.w["xB"]).view(6, 40, 256)
+    a = K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode=(1, 1))
+    b = K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode="steps")
+    assert torch.equal(a, b)
