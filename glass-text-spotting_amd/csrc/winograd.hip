@@ -448,8 +448,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino128_f32(WinoParams p) {
   const unsigned rowy = (unsigned)p.W * ldy4, rowr = (unsigned)p.W * ldr4;
   unsigned yoff[16];                              // [pass][b][a]: byte offset of the output pixel, OOB if it does not exist
   float4 rres[16];
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
+  // tile -> pixel offsets of one pass: computed TWICE (mul-high divisions, ~40 instructions) - for the residual loads before
+  // the LDS transposition and for the output offsets after it.  Kept across the transposition, the sixteen output offsets
+  // pushed the register allocation over: 8 registers went to scratch and the scratch stores showed up as 12.5 % more HBM
+  // writes than the output tensor (PMC WRITE_SIZE, scripts/exp_write_size.py; round 5).
+  auto pass_pixels = [&](int pass, unsigned ld4, unsigned row4, unsigned coff, unsigned (&off)[4]) {
     const int tt = t0 + pass * 8 + ts;
     const bool tv = tt < p.ntiles;
     const int n = fast_div(tt, tpi, p.magic_tpi);
@@ -457,19 +460,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino128_f32(WinoParams p) {
     const int th = fast_div(rem, p.TW, p.magic_tw);
     const int tw = rem - th * p.TW;
     const unsigned pix = (unsigned)((n * p.H + 2 * th) * p.W + 2 * tw);
-    const unsigned yb = pix * ldy4 + (unsigned)(p.ycoff + co) * 4u;
-    const unsigned rb = pix * ldr4 + (unsigned)co * 4u;
+    const unsigned base = pix * ld4 + coff;
     const bool h1 = 2 * th + 1 < p.H, w1 = 2 * tw + 1 < p.W;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const bool ok = tv && (a == 0 || h1) && (b == 0 || w1);
-        yoff[pass * 4 + b * 2 + a] = ok ? yb + (a ? rowy : 0u) + (b ? ldy4 : 0u) : OOB;
-        if (p.res_mode == 1)
-          rres[pass * 4 + b * 2 + a] = __builtin_bit_cast(
-              float4, __builtin_amdgcn_raw_buffer_load_b128(rr, ok ? rb + (a ? rowr : 0u) + (b ? ldr4 : 0u) : OOB, 0, 0));
+        off[b * 2 + a] = ok ? base + (a ? row4 : 0u) + (b ? ld4 : 0u) : OOB;
       }
+  };
+  if (p.res_mode == 1) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      unsigned ro[4];
+      pass_pixels(pass, ldr4, rowr, (unsigned)co * 4u, ro);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rres[pass * 4 + i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, ro[i], 0, 0));
+    }
   }
   float* zs = smem;
 #pragma unroll
@@ -482,6 +490,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino128_f32(WinoParams p) {
       zs[((wv * 2 + 0) * T2 + row) * ZLD2 + col] = m0 + m1 + m2;
       zs[((wv * 2 + 1) * T2 + row) * ZLD2 + col] = m1 - m2 - m3;
     }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    unsigned yo[4];
+    pass_pixels(pass, ldy4, rowy, (unsigned)(p.ycoff + co) * 4u, yo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yoff[pass * 4 + i] = yo[i];
+  }
   __syncthreads();
   // ReLU before (2) / after (1) the residual add as an unconditional max: max(x, qNaN) = x keeps "no ReLU" exact,
   // NaN inputs included (max(x, -inf) would turn a NaN into -inf)
