@@ -49,8 +49,9 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200 = ~5.6 s of 8-image steps: long enough for an "
+                                                              "outside clock / utilisation sampler to corroborate the line)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gc-freeze", type=int, default=1, help="gc.freeze() the warm heap after warmup (0 = off)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--side", type=int, default=SIDE)
