@@ -286,7 +286,7 @@ def dry_run(args, rank, world, dist) -> None:
         if world > 1:
             line["cpu_baseline_ref"] = last_cpu_baseline_on_file()
         assert line["n_gpus"] == args.gpus == comm["world_size"]
-        print(json.dumps(line), flush=True)
+        emit_line(line)
 
 
 def last_cpu_baseline_on_file():
@@ -330,6 +330,19 @@ def self_launch(args) -> int:
     return launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
 
 
+_REAL_STDOUT = None
+
+
+def emit_line(line: dict) -> None:
+    """the ONE line of the contract, to the process's real stdout (see main: fd 1 is stderr while the run lasts)"""
+    data = (json.dumps(line) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, data)
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -339,6 +352,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL prints a version banner when a
+    # communicator is created, gloo its connection chatter), so file descriptor 1 is pointed at stderr for the whole run and the
+    # line goes to the saved descriptor at the very end (emit_line)
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+    if os.environ.get("GLASS_BENCH_STDOUT_NOISE"):                # (test hook: what a chatty native library does)
+        os.write(1, b"noise from a native library on file descriptor 1\n")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
     if os.environ.get("GLASS_BENCH_DRYRUN"):
@@ -373,10 +395,17 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # GLASS_BENCH_RCCL_WORLD1=1: a ONE-rank process group on the RCCL backend - communicator creation, the device-side barrier and
+    # the per-step all_gather_into_tensor of the word records execute on this GPU (with one rank the collective is a copy).  The
+    # only way to put RCCL itself through bench.py's code path on a 1-GPU lease; `n_gpus` stays 1.
+    if world > 1 or os.environ.get("GLASS_BENCH_RCCL_WORLD1") == "1":
         import torch.distributed as dist
-        from glass_amd.distributed import init_process_group, pin_to_gpu_numa_node
+        from glass_amd.distributed import free_port, init_process_group, pin_to_gpu_numa_node
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # per rank, before the model is built: which device this rank drives and which CPUs it was pinned to (its GPU's NUMA node)
         print(f"[bench rank {rank}] LOCAL_RANK {local_rank} -> cuda:{dev_index} ({torch.cuda.get_device_name(dev_index)}) "
               + json.dumps(pin_to_gpu_numa_node(dev_index)), file=sys.stderr, flush=True)
@@ -770,7 +799,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         assert line["n_gpus"] == args.gpus == line["comm"]["world_size"], (line["n_gpus"], args.gpus, line["comm"])
-        print(json.dumps(line), flush=True)
+        emit_line(line)
 
 
 if __name__ == "__main__":

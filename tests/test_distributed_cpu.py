@@ -411,3 +411,15 @@ def test_numa_pinning_helpers(tmp_path):
     assert rep["pinned"] is False and os.sched_getaffinity(0) == before and rep["cpus_after"] == len(before)
     pre = D.preflight_report(8, "nccl")
     assert pre["world_size"] == 8 and pre["devices_visible"] == 0 and pre["timeout_s"] == 120.0
+
+
+def test_stdout_carries_one_line_even_when_native_libraries_write_to_it():
+    """RCCL prints a version banner on stdout when a communicator is created (seen on MI355X with a one-rank nccl group,
+    profiles/r05_bench_rccl_world1.json: five extra lines), gloo its connection chatter: bench.py points file descriptor 1 at
+    stderr for the whole run and writes the ONE JSON line to the saved descriptor - with noise injected on fd 1 in every rank."""
+    import json
+    p = _run_bench({"GLASS_BENCH_DRYRUN": "1", "GLASS_BENCH_STDOUT_NOISE": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "0", "--batch", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, p.stdout
+    assert p.stderr.count("noise from a native library") == 2
