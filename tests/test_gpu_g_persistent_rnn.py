@@ -174,3 +174,21 @@ def test_decoder_shapes_the_persistent_kernel_does_not_take_run_the_step_kernels
     a = K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode=(1, 1))
     b = K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode="steps")
     assert torch.equal(a, b)
+
+
+def test_persistent_decoder_honours_the_temperature():
+    """`output = self.fc(output) * self.temperature` (reference prediction_aster.py DecoderUnit.forward): a temperature other than
+    1 changes the probabilities (not the arg-max) - same results as the step kernels"""
+    import numpy as np
+    from glass_amd.ops import native as K
+    dec, _ = _decoder()
+    w = dict(dec.w)
+    w["temperature"] = 0.6
+    x = torch.randn((20, 32, 256), generator=torch.Generator().manual_seed(9)).to(_dev())
+    ri = torch.zeros((20,), dtype=torch.int32, device=_dev())
+    xproj = K.linear(x.view(20 * 32, 256), dec.w["xW"], dec.w["xB"]).view(20, 32, 256)
+    a = K.attention_decode(x, xproj, w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode=(1, 1)).cpu().numpy()
+    b = K.attention_decode(x, xproj, w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode="steps").cpu().numpy()
+    c = K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode=(1, 1)).cpu().numpy()
+    live = b.sum(-1) > 0
+    assert float(np.abs(a - b)[live].max()) < 1e-5 and float(np.abs(a - c).max()) > 1e-4
