@@ -49,6 +49,9 @@ class GlassLibraryError(RuntimeError):
 DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 
 
+ABI_VERSION = 4      # what csrc/common.hip glass_abi_version() returns: bumped whenever include/glass_hip.h gains or changes an entry
+
+
 def sources() -> List[str]:
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
