@@ -121,6 +121,8 @@ class ConvMeter:
                 path = path[:-1]
             elif path == "winograd43":                  # F(4x4,3x3): 36 MACs per (ceil(H/4) x ceil(W/4)) tile, channel pair
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 3) // 4) * ((y.shape[2] + 3) // 4) * 36 * cout * cin
+            elif path == "pointwise_split":             # every fp32 product as 9 (or 6) exact bf16 piece products on the bf16 matrix cores
+                ex = float(getattr(self.K.routing_of(w), "split", 0) or 9) * algo
             elif path.startswith("winograd"):           # 16 MACs per (ceil(H/2) x ceil(W/2)) tile, channel pair
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * ((y.shape[2] + 1) // 2) * 16 * cout * cin
             else:
@@ -173,7 +175,7 @@ class ConvMeter:
 
     def summary(self):
         out = {k: {"launches": 0, "ms": 0.0, "algo_flops": 0.0, "exec_flops": 0.0}
-               for k in ("winograd43", "winograd128", "winograd", "pointwise", "direct", "direct_fp16", "packed_fp16", "fused_stem")}
+               for k in ("winograd43", "winograd128", "winograd", "pointwise", "pointwise_split", "direct", "direct_fp16", "packed_fp16", "fused_stem")}
         for p, _xs, _ws, _st, _res, algo, ex, ms in self._launches():
             f = out[p]
             f["launches"] += 1
@@ -661,13 +663,14 @@ def main():
                  "winograd128": "conv3x3_wino128_f32 (Winograd F(2x2,3x3), fp32 MFMA, 32 tiles x 128 channels per workgroup)",
                  "winograd": "conv3x3_wino_f32 (Winograd F(2x2,3x3), fp32 MFMA, 64 tiles x 64 channels per workgroup)",
                  "pointwise": "conv1x1_pw_f32 (fp32 MFMA 16x16x4 weight-streaming 1x1 GEMM)",
+                 "pointwise_split": "conv1x1_pw_split (1x1 GEMM, exact fp32 products as nine bf16 piece products: bf16 MFMA 16x16x32, fp32 accumulate; executed_* count the bf16 MFMA FLOP against the bf16 peak)",
                  "direct": "conv_igemm_f32 (fp32 MFMA implicit-GEMM conv/linear)",
                  "direct_fp16": "conv_igemm_f32<..., HALF> (fp16 MFMA implicit-GEMM conv/linear, fp32 accumulate)",
                  "packed_fp16": "conv_h16_kernel (fp16 MFMA 16x16x32 weight-streaming implicit-GEMM conv on fp16 tensors, fp32 accumulate)",
                  "fused_stem": "backbone_stem_fused_kernel + local_stem_fused_kernel (conv + ReLU + max-pool fused stems, fp32 MFMA 32x32x2)"}
-        PKEY = {"winograd43": "conv3x3_wino43_f32", "winograd128": "conv3x3_wino128_f32", "winograd": "conv3x3_wino_f32", "pointwise": "conv1x1_pw_f32", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
+        PKEY = {"winograd43": "conv3x3_wino43_f32", "winograd128": "conv3x3_wino128_f32", "winograd": "conv3x3_wino_f32", "pointwise": "conv1x1_pw_f32", "pointwise_split": "conv1x1_pw_split", "direct": "conv_igemm_f32_64x64",     # direct: its busiest instantiation
                 "direct_fp16": "conv_igemm_f16", "packed_fp16": "conv_h16_kernel", "fused_stem": "backbone_stem_fused_kernel"}
-        PEAK = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else FP16_MFMA_PEAK_TFLOPS
+        PEAK = PEAK_DEFAULT = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else FP16_MFMA_PEAK_TFLOPS
         dom = max(fam, key=lambda k: fam[k]["ms"])            # the dominant kernel by time
         # PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate
         # rocprofv3 --pmc runs, gfx950 x2 read correction applied; scripts/pmc_make_summary.py)
@@ -691,12 +694,13 @@ def main():
             if f["launches"] == 0:
                 return None
             sec = f["ms"] * 1e-3
+            PEAK = FP16_MFMA_PEAK_TFLOPS if k == "pointwise_split" else PEAK_DEFAULT      # bf16 peak = fp16 peak
             pj = pmc_all.get(PKEY[k], {}) if isinstance(pmc_all.get(PKEY[k], {}), dict) else {}
             return {"kernel": KNAME[k], "launches_per_step": f["launches"], "kernel_ms_per_step": f["ms"],
                     "avg_launch_ms": f["ms"] / f["launches"],
                     "executed_tflops": f["exec_flops"] / sec / 1e12, "executed_frac": f["exec_flops"] / sec / 1e12 / PEAK,
                     "algorithmic_tflops": f["algo_flops"] / sec / 1e12,
-                    "algorithmic_frac": f["algo_flops"] / sec / 1e12 / PEAK,
+                    "algorithmic_frac": f["algo_flops"] / sec / 1e12 / PEAK_DEFAULT,
                     "algorithmic_gflop_per_launch": f["algo_flops"] / f["launches"] / 1e9,
                     "traffic": pj.get("hbm_bytes_per_launch_corrected"), "mfma_util_percent_pmc": pj.get("MfmaUtil_percent"),
                     # the same family's weighted average launch in the committed rocprofv3 --kernel-trace --stats table

@@ -95,6 +95,16 @@ def _parse_rnn(v):
     return (nd, ng)
 
 
+def _parse_split(v) -> int:
+    try:
+        n = int(v)
+    except (TypeError, ValueError):
+        n = -1
+    if n not in (0, 6, 9):
+        raise GlassLibraryError(f"unknown 1x1 split routing {v!r} (0 | 9 | 6)")
+    return n
+
+
 class Routing:
     """Which kernel a conv / linear launch takes, as VALUES that travel with the layer (no global state, re-entrant
     per model): a model builds one `Routing` at construction (environment variables GLASS_* give the defaults, `MODEL.
@@ -119,14 +129,18 @@ class Routing:
                   100 rows, res4 / res5 3x3, the 11-row predictors) as a split-K launch + ordered reduction (GLASS_SPLITK=0)
       small_grid  3x3 layers whose F(4x4) grid does not fill the chip pick their Winograd form by rounds x workgroup time,
                   incl. the F(2x2) body + strip form for odd widths (GLASS_SMALL_GRID=0: the batch-8 rules only)
+      split       1x1 layers (Cin % 32 == 0, Cout % 128 == 0) on the bf16 matrix cores with EXACT fp32 products: each fp32
+                  operand as three bf16 pieces, 9 = all nine piece products (the sum an fp32 fma chain accumulates, in another
+                  order; the default), 6 = without the three products below 2^-23 (opt-in, measurement only), 0 = the fp32-MFMA
+                  kernels (GLASS_PW_SPLIT=0 | 6 | 9; csrc/pointwise_split.hip)
       pooled_fusion  P2P3Fusion's two 1x1 convolutions AFTER the recognizer pooler (on the pooled bins) instead of on the whole
                   p2 / p3 maps - RoIAlign and the fusion are both linear (GLASS_POOLED_FUSION=0: whole-map fusion, then pool)"""
-    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion", "rnn", "splitk", "small_grid")
+    __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion", "rnn", "splitk", "small_grid", "split")
 
     def __init__(self, precision: Optional[str] = None, winograd: Optional[bool] = None, f43: Optional[bool] = None, pw=None,
                  h16: Optional[bool] = None, local_stem: Optional[bool] = None, stem: Optional[bool] = None,
                  ragged: Optional[bool] = None, pooled_fusion: Optional[bool] = None, rnn=None,
-                 splitk: Optional[bool] = None, small_grid: Optional[bool] = None):
+                 splitk: Optional[bool] = None, small_grid: Optional[bool] = None, split: Optional[int] = None):
         e = os.environ.get
         self.precision = precision or e("GLASS_CONV_PRECISION", "fp32")
         if self.precision not in _PRECISIONS:
@@ -142,6 +156,7 @@ class Routing:
         self.rnn = _parse_rnn(e("GLASS_RNN", "1x1")) if rnn is None else _parse_rnn(rnn)
         self.splitk = (e("GLASS_SPLITK", "1") != "0") if splitk is None else bool(splitk)
         self.small_grid = (e("GLASS_SMALL_GRID", "1") != "0") if small_grid is None else bool(small_grid)
+        self.split = _parse_split(e("GLASS_PW_SPLIT", "9") if split is None else split)
 
     def replace(self, **kw) -> "Routing":
         r = Routing.__new__(Routing)
@@ -151,6 +166,7 @@ class Routing:
             raise TypeError(f"unknown routing fields {sorted(kw)}")
         if r.precision not in _PRECISIONS:
             raise GlassLibraryError(f"unknown conv precision {r.precision!r}")
+        r.split = _parse_split(r.split)
         return r
 
     @property
@@ -238,6 +254,14 @@ def set_pointwise(enabled: bool) -> bool:
     return prev
 
 
+def set_pw_split(products: int) -> int:
+    """raw-tensor default: 1x1 layers (Cin % 32 == 0, Cout % 128 == 0, >= 4096 pixels) on the bf16-split kernel with 9 (the exact
+    product, default) or 6 piece products, 0: the fp32-MFMA kernels (see Routing.split).  Returns the previous setting."""
+    prev = _DEFAULT.split
+    _DEFAULT.split = _parse_split(products)
+    return prev
+
+
 def winograd_pack(w: torch.Tensor, f43=False) -> torch.Tensor:
     """w [Cout,3,3,Cin] -> packed U for glass_conv3x3_winograd_nhwc (16*Cout*Cin floats) or, with f43 True, for
     glass_conv3x3_winograd43_nhwc (36*Cout*Cin floats); f43 == "pw": w [Cout,1,1,Cin] -> the fragment-ordered weights of
@@ -254,6 +278,11 @@ def winograd_pack(w: torch.Tensor, f43=False) -> torch.Tensor:
         u = torch.empty((int(L.glass_conv_h16_weight_halves(Cout, KH, KW, Cin)),), dtype=torch.float16, device=w.device)
         check(L.glass_conv_h16_pack_weights(c_void_p(_dev(w, "w")), Cout, KH, KW, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())),
               "glass_conv_h16_pack_weights")
+        return u
+    if f43 == "pws":
+        u = torch.empty((int(L.glass_pointwise_split_weight_bytes(Cout, Cin)),), dtype=torch.uint8, device=w.device)
+        check(L.glass_pointwise_split_pack_weights(c_void_p(_dev(w, "w")), Cout, Cin, c_void_p(_dev(u)), c_void_p(stream_handle())),
+              "glass_pointwise_split_pack_weights")
         return u
     if f43 == "pw":
         nf, fn, what = L.glass_pointwise_weight_floats, L.glass_pointwise_pack_weights, "glass_pointwise_pack_weights"
@@ -278,6 +307,7 @@ def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int, body: bool = False) ->
 
 
 NUM_CUS = 256
+_SPLIT_MIN_PX = int(os.environ.get("GLASS_PW_SPLIT_MIN_PX", "4096"))     # below: the per-workgroup weight stream is not amortised
 
 
 def _small_grid_3x3(N: int, H: int, W: int, Cout: int, Cin: int, can_body: bool, f43_ok: bool):
@@ -363,12 +393,12 @@ def _probe_desc(Cout: int, KH: int, KW: int, Cin: int) -> ConvDesc:
     return ConvDesc(1, 16, 16, Cin, Cout, KH, KW, 1, 1, ph, pw, 16 + 2 * ph - KH + 1, 16 + 2 * pw - KW + 1, Cin, Cout, 0, 1, 0, 0, 0)
 
 
-def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str, stride=1, ragged: bool = False) -> list:
+def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str, stride=1, ragged: bool = False, split: int = 0) -> list:
     """which packed forms a [Cout,KH,KW,Cin] weight can be asked for under `precision` (the routing of conv2d_nhwc);
     "all": every form the layer supports (micro-benchmarks that force kernels across precisions).  `stride` != 1 rules the
     Winograd forms out (stride-2 3x3 layers were carrying 52/9 of their size in packs no launch could take)."""
     if precision == "all":
-        return pack_kinds(Cout, KH, KW, Cin, "fp32", stride, ragged) + pack_kinds(Cout, KH, KW, Cin, "fp16", stride)
+        return pack_kinds(Cout, KH, KW, Cin, "fp32", stride, ragged, split=9) + pack_kinds(Cout, KH, KW, Cin, "fp16", stride)
     L, d = lib(), _probe_desc(Cout, KH, KW, Cin)
     kinds = []
     if precision == "fp32":
@@ -381,6 +411,8 @@ def pack_kinds(Cout: int, KH: int, KW: int, Cin: int, precision: str, stride=1, 
                     kinds.append("col1")     # the layer meets maps of width 4 k + 1 (caller's hint): strip weights of the last column
         if KH == 1 and KW == 1 and L.glass_pointwise_supported(ctypes.byref(d)):
             kinds.append("pw")
+        if split and KH == 1 and KW == 1 and L.glass_pointwise_split_supported(ctypes.byref(d)):
+            kinds.append("pws")
     elif Cin % 64 == 0 and L.glass_conv_h16_supported(ctypes.byref(d), 1):
         kinds.append("h16")
     return kinds
@@ -401,7 +433,7 @@ def prepare_conv_weights(w: torch.Tensor, precision: Optional[str] = None, strid
     precision = precision or (load.precision if load is not None else _DEFAULT.precision)
     Cout, KH, KW, Cin = w.shape
     if w.is_cuda:
-        for kind in pack_kinds(Cout, KH, KW, Cin, precision, stride, ragged):
+        for kind in pack_kinds(Cout, KH, KW, Cin, precision, stride, ragged, split=(load.split if load is not None else _DEFAULT.split)):
             cw.packs[kind] = winograd_pack(w, kind)
         if cw.packs and load is None:
             torch.cuda.current_stream().synchronize()      # other streams (pipelined steps) may launch with it next
@@ -519,6 +551,13 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     # to end (five alternating runs: 280.3 vs 279.7); the Cout = 128 layers still are not (279.5), and below 8192 pixels the
     # per-workgroup weight stream is not amortised (batch 2: 2-4x SLOWER than the direct kernel).
     px = N * Ho * Wo
+    if winograd in ("pws9", "pws6"):                 # forced: the exact-product bf16-split 1x1 kernel (tests, scripts)
+        if not lib().glass_pointwise_split_supported(ctypes.byref(d)):
+            raise GlassLibraryError(f"winograd={winograd!r} but glass_pointwise_split_supported() rejects this layer")
+        return launch("glass_conv1x1_pointwise_split_nhwc", "pointwise_split", x, _packed(w, wt, "pws"), int(winograd[3]))
+    if (winograd is None and rt.split and KH == 1 and KW == 1 and px >= _SPLIT_MIN_PX and
+            lib().glass_pointwise_split_supported(ctypes.byref(d)) and (not isinstance(w, ConvWeight) or "pws" in w.packs)):
+        return launch("glass_conv1x1_pointwise_split_nhwc", "pointwise_split", x, _packed(w, wt, "pws"), rt.split)
     if (winograd is None and rt.pw and KH == 1 and KW == 1 and
             (rt.pw == "all" or (Cin >= 256 and Cout >= 256 and px >= 16384) or (Cin >= 512 and Cout >= 512 and px >= 8192))
             and lib().glass_pointwise_supported(ctypes.byref(d))):

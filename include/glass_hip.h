@@ -159,6 +159,20 @@ int glass_pointwise_pack_weights(const float* w, int Cout, int Cin, float* u_pac
 int glass_conv1x1_pointwise_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                  const float* residual, float* y, glass_stream_t stream);
 
+/* The same 1x1 convolution with its fp32 products computed EXACTLY on the bf16 matrix cores (csrc/pointwise_split.hip):
+ * every fp32 operand is the exact sum of three bf16 pieces (8 + 8 + 8 significant bits), the product of two pieces is exact
+ * in fp32, and the nine piece products accumulate in fp32 - the same sum of exact products an fp32 fma chain accumulates,
+ * in 9 x 16 instead of 8 x 32 matrix cycles per 32 input channels.  Same descriptor / epilogue as glass_conv1x1_pointwise_nhwc,
+ * results equal to glass_conv2d_nhwc up to summation order.  `u_packed`: glass_pointwise_split_pack_weights lays W [Cout][Cin]
+ * out as three bf16 planes in MFMA fragment order (glass_pointwise_split_weight_bytes = 6 Cout Cin bytes), once per layer.
+ * `products`: 9 (the exact product; the model path) or 6 (without the three piece pairs below 2^-23 relative: measurement
+ * only).  Inputs must be finite (inf - inf in the split).                                                               */
+int glass_pointwise_split_supported(const glass_conv_desc* d);
+size_t glass_pointwise_split_weight_bytes(int Cout, int Cin);
+int glass_pointwise_split_pack_weights(const float* w, int Cout, int Cin, void* u_packed, glass_stream_t stream);
+int glass_conv1x1_pointwise_split_nhwc(const glass_conv_desc* d, const float* x, const void* u_packed, const float* bias,
+                                       const float* residual, float* y, int products, glass_stream_t stream);
+
 /* Fused head of the local-crop feature extractor (reference glass/modeling/fusion/local_feature_extraction.py:103-112):
  * conv0_1 (3x3, 3->16) + BN + ReLU, conv0_2 (3x3, 16->32) + BN + ReLU, maxpool1 2x2 in ONE kernel - the two intermediate
  * maps stay in LDS.  x [R,H,W,4] NHWC4 crops, w1 [16][3][3][4] / b1 [16], w2 [32][3][3][16] / b2 [32] (BatchNorm folded),

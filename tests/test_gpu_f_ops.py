@@ -953,6 +953,7 @@ def test_pointwise_matches_direct_and_torch(case):
     N, H, W, Cin, Cout, stride, relu, res_mode, strided = case
     dev = _dev()
     K.set_pointwise("all")
+    prev_split = K.set_pw_split(0)                 # this test is about the fp32-MFMA 1x1 kernel
     x = _rand((N, Cin, H, W), 71)
     w = _rand((Cout, Cin, 1, 1), 72, (2.0 / Cin) ** 0.5)
     b = _rand((Cout,), 73, 0.1)
@@ -1001,4 +1002,106 @@ def test_pointwise_matches_direct_and_torch(case):
     ed = float((y - yd).abs().max()) / scale
     print(f"pointwise {case[:6]}: vs fp64 {e:.2e}, vs implicit-GEMM kernel {ed:.2e} (of range)")
     K.set_pointwise(True)
+    K.set_pw_split(prev_split)
     assert e <= 5e-6 and ed <= 5e-6
+
+
+@pytest.mark.parametrize("products", [9, 6])
+@pytest.mark.parametrize("case", PW_CASES + [(8, 32, 32, 512, 2048, 1, 1, 1, None), (1, 64, 64, 1024, 128, 1, 0, 0, (256, 64))])
+def test_pointwise_split_matches_direct_and_torch(case, products):
+    """glass_conv1x1_pointwise_split_nhwc (every fp32 product as bf16 piece products on the bf16 matrix cores, fp32
+    accumulate) vs torch fp64 and vs glass_conv2d_nhwc.  Nine products ARE the exact product, so the kernel is held to the
+    fp32-MFMA kernels' own bound (5e-6 of the output range, K up to 2048 terms) and must not be further from fp64 than
+    the fp32-MFMA kernels are (the weight-streaming 1x1 kernel, which like this one runs ONE accumulator down the whole K, or
+    the implicit-GEMM kernel) by more than rounding noise; the six-product form (opt-in, measurement only) drops < 2^-23
+    per product and is held to the same bound."""
+    from glass_amd.ops import native as K
+    N, H, W, Cin, Cout, stride, relu, res_mode, strided = case
+    dev = _dev()
+    x = _rand((N, Cin, H, W), 71)
+    w = _rand((Cout, Cin, 1, 1), 72, (2.0 / Cin) ** 0.5)
+    b = _rand((Cout,), 73, 0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride)
+    res = None
+    if res_mode == 1:
+        res = _rand(tuple(ref.shape), 74)
+    elif res_mode == 2:
+        res = _rand((N, Cout, ref.shape[2] // 2, ref.shape[3] // 2), 74)
+    if relu == 2:
+        ref = F.relu(ref)
+    if res_mode == 1:
+        ref = ref + res.double()
+    elif res_mode == 2:
+        ref = ref + F.interpolate(res.double(), scale_factor=2.0, mode="nearest")
+    if relu == 1:
+        ref = F.relu(ref)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    xd, wd = nhwc(x).to(dev), nhwc(w).to(dev)
+    rd = None if res is None else nhwc(res).to(dev)
+    kw = dict(stride=stride, relu=relu, residual=rd, res_mode=res_mode)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    force = f"pws{products}"
+    if strided is None:
+        y = torch.full((N, Ho, Wo, Cout), float("nan"), device=dev)     # every output must be written
+        K.conv2d_nhwc(xd, wd, b.to(dev), out=y, winograd=force, **kw)
+        assert K.last_conv_path() == "pointwise_split"
+        yd = K.conv2d_nhwc(xd, wd, b.to(dev), winograd=False, **kw)
+        assert K.last_conv_path() == "direct"
+        yp = K.conv2d_nhwc(xd, wd, b.to(dev), routing=K.default_routing().replace(split=0, pw="all"), **kw)
+        assert K.last_conv_path() == "pointwise"
+    else:
+        ld, coff = strided
+        yp = None
+        buf = torch.full((N, Ho, Wo, ld), 7.0, device=dev)
+        bufd = torch.full((N, Ho, Wo, ld), 7.0, device=dev)
+        buf[..., coff:coff + Cout] = float("nan")
+        K.conv2d_nhwc(xd, wd, b.to(dev), out=buf, out_coff=coff, winograd=force, **kw)
+        assert K.last_conv_path() == "pointwise_split"
+        K.conv2d_nhwc(xd, wd, b.to(dev), out=bufd, out_coff=coff, winograd=False, **kw)
+        torch.cuda.synchronize()
+        assert float((buf[..., :coff] - 7.0).abs().max()) == 0.0
+        assert coff + Cout == ld or float((buf[..., coff + Cout:] - 7.0).abs().max()) == 0.0
+        y, yd = buf[..., coff:coff + Cout], bufd[..., coff:coff + Cout]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all()), "unwritten or non-finite outputs"
+    scale = float(ref.abs().max())
+    e = float((y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max()) / scale
+    e_direct = float((yd.cpu().permute(0, 3, 1, 2).double() - ref).abs().max()) / scale
+    e_pw = e_direct if yp is None else float((yp.cpu().permute(0, 3, 1, 2).double() - ref).abs().max()) / scale
+    ed = float((y - yd).abs().max()) / scale
+    print(f"pointwise split x{products} {case[:6]}: vs fp64 {e:.2e} (fp32-MFMA kernels: implicit GEMM {e_direct:.2e}, weight-streaming {e_pw:.2e}), "
+          f"vs implicit-GEMM kernel {ed:.2e} (of range)")
+    assert e <= 5e-6 and ed <= 5e-6 and e <= 1.5 * max(e_direct, e_pw) + 2e-7
+
+
+def test_pointwise_split_is_exact_where_fp32_is():
+    """Operands whose products and partial sums are all exactly representable (integers < 2^11 times powers of two, K = 256): an
+    fp32 fma chain is exact in ANY order, so the nine-product kernel must return the float64 result bit for bit - the three
+    low pieces carry real bits here (operands with 20 significant bits), a dropped or mis-scaled piece product would show."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cin, Cout = 2, 32, 64, 256, 128
+    # x: 20-bit integers scaled by 2^-12 (pieces h, m, l all non-zero), w: small integers -> products < 2^24 each?  keep sums exact:
+    # |x| < 2^20, |w| <= 4, K = 256 -> |sum| < 2^20 * 4 * 256 = 2^30 with unit 2^-12 spacing needs 42 bits: NOT exact in fp32.
+    # So: x = a * 2^-8 with |a| < 2^12 (12 significant bits, two pieces), w = b * 2^-4 with |b| < 2^4 -> products < 2^16 units,
+    # sums < 2^24 units of 2^-12: exact in fp32 in any order.
+    a = torch.randint(-(1 << 12) + 1, 1 << 12, (N, H, W, Cin), generator=g).float() * 2.0 ** -8
+    bq = torch.randint(-15, 16, (Cout, 1, 1, Cin), generator=g).float() * 2.0 ** -4
+    ref = (a.reshape(-1, Cin).double() @ bq.reshape(Cout, Cin).double().t()).float().reshape(N, H, W, Cout)
+    y9 = K.conv2d_nhwc(a.to(dev), bq.to(dev), None, winograd="pws9")
+    yd = K.conv2d_nhwc(a.to(dev), bq.to(dev), None, winograd=False)
+    torch.cuda.synchronize()
+    assert torch.equal(yd.cpu(), ref), "the implicit-GEMM kernel itself is not exact on this input: the test's premise is wrong"
+    assert torch.equal(y9.cpu(), ref)
+    # three-piece operands: x with 24 significant bits, w = +-2^k (one piece): every product is exact, partial sums are not
+    # in general, so compare the split kernel with float64 at fp32 rounding (one ulp of the largest partial sum per add)
+    x24 = (torch.randint(1 << 23, 1 << 24, (N, H, W, Cin), generator=g).float() * 2.0 ** -24)
+    wp2 = (2.0 ** torch.randint(-3, 3, (Cout, 1, 1, Cin), generator=g).float()) * (torch.randint(0, 2, (Cout, 1, 1, Cin), generator=g).float() * 2 - 1)
+    r64 = x24.reshape(-1, Cin).double() @ wp2.reshape(Cout, Cin).double().t()
+    y = K.conv2d_nhwc(x24.to(dev), wp2.to(dev), None, winograd="pws9").cpu().reshape(-1, Cout).double()
+    ydir = K.conv2d_nhwc(x24.to(dev), wp2.to(dev), None, winograd=False).cpu().reshape(-1, Cout).double()
+    bound = Cin * 2.0 ** -24 * float(x24.abs().max()) * 4.0 * Cin ** 0.5     # sqrt(K) rounding walk on sums up to K * max|x w|
+    e9, edir = float((y - r64).abs().max()), float((ydir - r64).abs().max())
+    print(f"24-bit operands: split x9 |err| {e9:.3e}, implicit GEMM {edir:.3e} (bound {bound:.3e})")
+    assert e9 <= bound and e9 <= 1.5 * edir

@@ -70,7 +70,7 @@ def test_roi_align_is_exact_beside_fp16_matrix_core_convolutions():
         ref = victim().clone()
         torch.cuda.synchronize()
         bad = sum(0 if torch.equal(o, ref) else 1 for o in _run_beside(victim, hammer, 300))
-        assert bad == 0, f"{name}: {bad} of 300 RoIAlign launches differ from the solo result while conv_h16_kernel runs beside them"
+        assert bad == 0, f"{name}: {bad} of 300 RoIAlign launches differ from the solo result while {beside} runs beside them"
 
 
 # (label, precision, x shape, w shape, stride/pad, expected path): one case per fp16 kernel instantiation
@@ -150,16 +150,22 @@ def test_fused_fp16_stem_is_deterministic_beside_the_fp32_winograd_kernel():
     assert all(torch.equal(o, ref) for o in outs)
 
 
-def test_fp32_kernels_are_exact_beside_fp16_matrix_core_convolutions():
+@pytest.mark.parametrize("beside", ["conv_h16_kernel", "conv1x1_pw_split"])
+def test_fp32_kernels_are_exact_beside_fp16_matrix_core_convolutions(beside):
     """the other direction: the fp32 path's kernels (Winograd, implicit GEMM + residual, pointwise, GC attention) with
-    conv_h16_kernel beside them - an fp32 step pipelined next to an fp16-mode step must not change by a bit"""
+    conv_h16_kernel beside them - an fp32 step pipelined next to an fp16-mode step must not change by a bit - and with the
+    bf16-split 1x1 kernel beside them, which is what two pipelined fp32 steps do to each other since round 5"""
     from glass_amd.ops import native as K
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
     hx = torch.randn((8, 64, 64, 256), device=dev)
     hw = K.prepare_conv_weights(torch.randn((256, 3, 3, 256), device=dev) * 0.05, "fp16")
+    hw1 = K.prepare_conv_weights(torch.randn((256, 1, 1, 256), device=dev) * 0.05, "fp32")
 
     def hammer():
+        if beside == "conv1x1_pw_split":
+            K.conv2d_nhwc(hx, hw1, None, winograd="pws9")
+            return
         prev = K.set_conv_precision("fp16")
         try:
             K.conv2d_nhwc(hx, hw, None, padding=1)
@@ -182,7 +188,8 @@ def test_fp32_kernels_are_exact_beside_fp16_matrix_core_convolutions():
         "winograd": lambda: K.conv2d_nhwc(x, w3, b, padding=1, relu=1, residual=r, res_mode=1, winograd=True),
         "implicit GEMM": lambda: K.conv2d_nhwc(x, w3, b, padding=1, relu=1, residual=r, res_mode=1, winograd=False),
         "1x1 (64 ch)": lambda: K.conv2d_nhwc(x, w1, None),
-        "pointwise": lambda: (K.set_pointwise("all"), K.conv2d_nhwc(x, wp, b, relu=1), K.set_pointwise(True))[1],
+        "pointwise": lambda: (K.set_pointwise("all"), K.conv2d_nhwc(x, wp, b, relu=1, routing=K.default_routing().replace(split=0)), K.set_pointwise(True))[1],
+        "pointwise split (bf16 MFMA)": lambda: K.conv2d_nhwc(x, wp, b, relu=1, winograd="pws9"),
         "gc attention": lambda: K.gc_attention_inplace(xg.clone(), 8, gw["w_mask"], gw["b_mask"], gw["w1"], gw["b1"], gw["ln_g"],
                                                        gw["ln_b"], gw["w2"], gw["b2"]),
     }
@@ -190,4 +197,4 @@ def test_fp32_kernels_are_exact_beside_fp16_matrix_core_convolutions():
         ref = victim().clone()
         torch.cuda.synchronize()
         bad = sum(0 if torch.equal(o, ref) else 1 for o in _run_beside(victim, hammer, 60))
-        assert bad == 0, f"{name}: {bad} of 60 launches differ from the solo result while conv_h16_kernel runs beside them"
+        assert bad == 0, f"{name}: {bad} of 60 launches differ from the solo result while {beside} runs beside them"
