@@ -631,6 +631,20 @@ def main():
                                                "workload than the metric's (504 vs 423 GMAC per image), PCIe-inclusive"}
             d = timed_loop(n_x, policy=True, depth=1)
             extras["runner_policy"]["latency_ms_per_step"] = d / n_x * 1e3
+        if args.precision == "fp32" and getattr(model.routing, "split", 0):
+            # the same steps with the 1x1 layers back on the fp32-MFMA kernels (Routing.split = 0 on the model's own routing
+            # object, which every layer's ConvWeight carries; both packed forms were built at load): the number to quote if
+            # exact fp32 products formed on the bf16 matrix cores are not accepted as fp32 arithmetic
+            split_was = model.routing.split
+            model.routing.split = 0
+            try:
+                n_s = max(4, min(args.steps, 60))
+                d = timed_loop(n_s)
+                extras["fp32_mfma_only"] = {"value": world * B * n_s / d, "unit": "images/sec", "ms_per_step": d / n_s * 1e3, "steps": n_s,
+                                            "what": "GLASS_PW_SPLIT=0: every convolution on v_mfma_f32_* (the 1x1 layers on conv1x1_pw_f32 / "
+                                                    "conv_igemm_f32 instead of conv1x1_pw_split); same model, same inputs, same run"}
+            finally:
+                model.routing.split = split_was
         d = timed_loop(n_x, depth=1)
         extras["latency_ms_per_step"] = d / n_x * 1e3          # one step at a time: what a single request waits
         extras["latency_note"] = (f"{n_x} steps run one at a time (--pipeline 1); `value` keeps {args.pipeline} steps in flight, so its "
@@ -779,6 +793,17 @@ def main():
                                     if (args.side, args.rois, args.workload) == (SIDE, ROIS, "e2e") else None},
         }
         line.update(extras)
+        if args.precision == "fp32":
+            line["arithmetic"] = ("fp32 operands, exact fp32 products, fp32 accumulation everywhere.  Convolutions on v_mfma_f32_16x16x4 / "
+                                  "32x32x2 (Winograd, implicit GEMM, stems)" +
+                                  ("; the 1x1 layers with Cin % 32 == 0, Cout % 128 == 0 form each fp32 product as the sum of its "
+                                   "nine exact bf16-piece products (v = h + m + l, 8 + 8 + 8 significant bits; "
+                                   "v_mfma_f32_16x16x32_bf16, fp32 accumulate): the same sum of exact products in another order - "
+                                   "csrc/pointwise_split.hip, DESIGN.md section 3; `fp32_mfma_only` is the same run without it"
+                                   if getattr(model.routing, "split", 0) == 9 else
+                                   "; GLASS_PW_SPLIT=6: the 1x1 layers DROP the three bf16-piece products below 2^-23 of each product "
+                                   "(opt-in, measurement only: not the exact product, not the headline)"
+                                   if getattr(model.routing, "split", 0) == 6 else ""))
         line["lib_source_sha16"] = source_sha16()
         # the persistent recurrent kernels' in-kernel waits are bounded: a hand-off that gave up raises a sticky status word
         # (bit 0 BiLSTM, bit 1 decoder) instead of hanging the GPU - 0 over the whole run or the line is not printed

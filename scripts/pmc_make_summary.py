@@ -23,7 +23,7 @@ stats_txt = sys.argv[4] if len(sys.argv) > 4 else None        # kernel_stats_ser
 HALF = MODE == "fp16s"               # fp16 instantiations of the fp32 template end in "true>"; the fp32 summary skips them
 KEYS = {"conv_h16_kernel": "conv_h16_kernel", "local_stem_fused_h16": "local_stem_fused_kernel<true>",
         "conv_igemm_f16": "conv_igemm_f32<", "conv3x3_wino43_f32": "conv3x3_wino43_f32", "roi_align_rotated_h16": "roi_align_rotated_kernel<true>",
-        "maxpool_h16": "maxpool_nhwc_kernel"} if HALF else {"conv3x3_wino43_f32": "conv3x3_wino43_f32", "conv1x1_pw_f32": "conv1x1_pw_f32", "conv3x3_wino128_f32": "conv3x3_wino128_f32", "conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, 1",
+        "maxpool_h16": "maxpool_nhwc_kernel"} if HALF else {"conv3x3_wino43_f32": "conv3x3_wino43_f32", "conv1x1_pw_f32": "conv1x1_pw_f32", "conv1x1_pw_split": "conv1x1_pw_split", "conv3x3_wino128_f32": "conv3x3_wino128_f32", "conv3x3_wino_f32": "conv3x3_wino_f32", "conv_igemm_f32_128x128": "conv_igemm_f32<2, 2, 2, 2, 1, 3, 32, 1",
         "conv_igemm_f32_64x128": "conv_igemm_f32<1, 4, 2, 1, 1, 4, 32, 1",
         "conv_igemm_f32_128x64": "conv_igemm_f32<2, 2, 2, 1, 1, 4, 32, 1",
         "conv_igemm_f32_64x64": "conv_igemm_f32<2, 2, 1, 1, 1, 8, 32, 1",
