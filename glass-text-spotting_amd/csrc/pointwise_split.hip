@@ -11,7 +11,8 @@
 // (the six-product form that leaves out the three terms below 2^-23 is a compile-time variant kept for measurement only:
 // NPROD), nothing is rounded before the accumulator: the result differs from the fp32-MFMA kernel's only by the order of the
 // additions (measured against float64: scripts/exp_pw_split.py).  Not representable: inf / nan inputs (h = inf, v - h = nan),
-// which the fp32 kernel would carry through; activations and weights of a forward pass are finite.
+// which the fp32 kernel would carry through; activations and weights of a forward pass are finite.  A piece below 2^-126 (the
+// low bits of an operand below ~2^-110) is a bf16 denormal and may be flushed by the matrix pipe: < 1e-37 |w| per product.
 //
 // Structure = pointwise.hip's (block = 16 PB pixels x 128 channels, 4 wavefronts x 32 channels, weights pre-split and
 // pre-packed in MFMA A-fragment order streaming L2 -> registers a k-tile ahead, pixels global -> registers -> LDS, one barrier

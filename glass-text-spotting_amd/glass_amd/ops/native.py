@@ -255,7 +255,7 @@ def set_pointwise(enabled: bool) -> bool:
 
 
 def set_pw_split(products: int) -> int:
-    """raw-tensor default: 1x1 layers (Cin % 32 == 0, Cout % 128 == 0, >= 4096 pixels) on the bf16-split kernel with 9 (the exact
+    """raw-tensor default: 1x1 layers (Cin % 32 == 0, Cout % 128 == 0, grid >= 1.5 x the chip: _use_split) on the bf16-split kernel with 9 (the exact
     product, default) or 6 piece products, 0: the fp32-MFMA kernels (see Routing.split).  Returns the previous setting."""
     prev = _DEFAULT.split
     _DEFAULT.split = _parse_split(products)
@@ -307,7 +307,14 @@ def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int, body: bool = False) ->
 
 
 NUM_CUS = 256
-_SPLIT_MIN_PX = int(os.environ.get("GLASS_PW_SPLIT_MIN_PX", "4096"))     # below: the per-workgroup weight stream is not amortised
+
+
+def _use_split(px: int, Cin: int, Cout: int) -> bool:
+    """the bf16-split 1x1 kernel pays when its 64-pixel x 128-channel blocks fill the chip one and a half times (below that the
+    per-workgroup weight stream is not amortised and the implicit-GEMM kernel's smaller tiles / split-K win: 1024 -> 256 at 64 x 64
+    is 0.036 -> 0.050 ms) and, for the two-k-tile layers (Cin 64: prologue + epilogue per block are most of its life), only on big
+    maps (64 -> 256 + residual: 0.93x at 8 x 256 x 256, 1.10x at 1 x 256 x 256) - profiles/r05_pw_split.txt, per-layer tables"""
+    return -(-px // 64) * (Cout // 128) >= 384 and (Cin >= 128 or px >= 262144)
 
 
 def _small_grid_3x3(N: int, H: int, W: int, Cout: int, Cin: int, can_body: bool, f43_ok: bool):
@@ -555,7 +562,7 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
         if not lib().glass_pointwise_split_supported(ctypes.byref(d)):
             raise GlassLibraryError(f"winograd={winograd!r} but glass_pointwise_split_supported() rejects this layer")
         return launch("glass_conv1x1_pointwise_split_nhwc", "pointwise_split", x, _packed(w, wt, "pws"), int(winograd[3]))
-    if (winograd is None and rt.split and KH == 1 and KW == 1 and px >= _SPLIT_MIN_PX and
+    if (winograd is None and rt.split and KH == 1 and KW == 1 and _use_split(px, Cin, Cout) and
             lib().glass_pointwise_split_supported(ctypes.byref(d)) and (not isinstance(w, ConvWeight) or "pws" in w.packs)):
         return launch("glass_conv1x1_pointwise_split_nhwc", "pointwise_split", x, _packed(w, wt, "pws"), rt.split)
     if (winograd is None and rt.pw and KH == 1 and KW == 1 and
