@@ -1074,6 +1074,26 @@ def test_pointwise_split_matches_direct_and_torch(case, products):
     assert e <= 5e-6 and ed <= 5e-6 and e <= 1.5 * max(e_direct, e_pw) + 2e-7
 
 
+def test_pointwise_split_reads_channel_slices_and_wide_residuals():
+    """the input as the first Cin channels of a wider buffer (ldx > Cin) and the residual as the first Cout channels of a wider
+    one (ldr > Cout): pixel strides come from the descriptor, not from the channel counts"""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    N, H, W, Cin, Cout = 2, 24, 40, 96, 256
+    xw = _rand((N, H, W, Cin + 32), 81).to(dev)
+    w = _rand((Cout, 1, 1, Cin), 82, (2.0 / Cin) ** 0.5).to(dev)
+    b = _rand((Cout,), 83, 0.1).to(dev)
+    rw = _rand((N, H, W, Cout + 64), 84).to(dev)
+    y = torch.full((N, H, W, Cout), float("nan"), device=dev)
+    K.conv2d_nhwc(xw, w, b, relu=1, residual=rw, res_mode=1, out=y, cin=Cin, winograd="pws9")
+    assert K.last_conv_path() == "pointwise_split"
+    ref = torch.relu(xw[..., :Cin].double().reshape(-1, Cin) @ w.double().reshape(Cout, Cin).t() + b.double() +
+                     rw[..., :Cout].double().reshape(-1, Cout)).reshape(N, H, W, Cout)
+    torch.cuda.synchronize()
+    e = float((y.double() - ref).abs().max()) / float(ref.abs().max())
+    assert bool(torch.isfinite(y).all()) and e <= 2e-6, e
+
+
 def test_pointwise_split_is_exact_where_fp32_is():
     """Operands whose products and partial sums are all exactly representable (integers < 2^11 times powers of two, K = 256): an
     fp32 fma chain is exact in ANY order, so the nine-product kernel must return the float64 result bit for bit - the three
