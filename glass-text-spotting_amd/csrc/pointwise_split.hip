@@ -2,22 +2,22 @@
 //
 // The fp32 MFMA (v_mfma_f32_16x16x4_f32: 2048 FLOP in 32 cycles) is the slowest matrix instruction of the chip, and the 1x1
 // layers of the backbone sit on it at 0.77 of its peak (pointwise.hip) while they move a fraction of what HBM could.  An
-// fp32 number is the EXACT sum of three bf16 numbers (8 + 8 + 8 significant bits: v = h + m + l, each piece a truncation, each
-// remainder an exact subtraction), and the product of two bf16 numbers (16 significant bits) is exact in fp32.  So
+// fp32 number is the EXACT sum of three bf16 numbers (8 + 8 + 8 significant bits: v = h + m + l, each piece a rounding to bf16,
+// each remainder an exact subtraction), and the product of two bf16 numbers (16 significant bits) is exact in fp32.  So
 //     x * w = sum over the nine pairs (xq, wr), q, r in {h, m, l}
 // holds EXACTLY, and nine v_mfma_f32_16x16x32_bf16 (16384 FLOP in 16 cycles each) with one fp32 accumulator compute the
 // same sum of products as eight v_mfma_f32_16x16x4_f32, with the same fp32 accumulation, in 9 x 16 = 144 instead of 8 x 32 =
 // 256 matrix cycles - on a pipe that, unlike the fp32 MFMA, does not share its issue with the vector ALU.  Nothing is dropped
 // (the six-product form that leaves out the three terms below 2^-23 is a compile-time variant kept for measurement only:
 // NPROD), nothing is rounded before the accumulator: the result differs from the fp32-MFMA kernel's only by the order of the
-// additions (measured against float64: scripts/exp_pw_split.py).  Not representable: inf / nan inputs (h = inf, v - h = nan),
-// which the fp32 kernel would carry through; activations and weights of a forward pass are finite.  A piece below 2^-126 (the
+// additions (measured against float64: scripts/exp_pw_split.py).  Not representable: inf / nan inputs (h = inf, v - h = nan) and
+// |v| > 3.39e38 (bf16(v) = inf), which the fp32 kernel would carry through; activations and weights of a forward pass are finite.  A piece below 2^-126 (the
 // low bits of an operand below ~2^-110) is a bf16 denormal and may be flushed by the matrix pipe: < 1e-37 |w| per product.
 //
 // Structure = pointwise.hip's (block = 16 PB pixels x 128 channels, 4 wavefronts x 32 channels, weights pre-split and
 // pre-packed in MFMA A-fragment order streaming L2 -> registers a k-tile ahead, pixels global -> registers -> LDS, one barrier
 // per k-tile, epilogue on registers with 16-byte stores), with the split of the pixels done once per block on the way into
-// LDS: three bf16 planes [pixel][32 k], 64-byte rows, 16-byte slots XOR-swizzled by (pixel / 4) % 4 so that the
+// LDS (4 v_sub + 1.5 v_cvt_pk + 2 unpacks per element): three bf16 planes [pixel][32 k], 64-byte rows, 16-byte slots XOR-swizzled by (pixel / 4) % 4 so that the
 // ds_read_b128 of a B fragment (lane = pixel lane & 15, k-octet lane >> 4) is conflict-free.
 #include "wino_common.h"
 
@@ -47,16 +47,21 @@ unsigned long long* g_pws_dbg = nullptr;
 #define PWS_STAMP(k) {}
 #endif
 
-// v = h + m + l exactly; the pieces are returned as fp32 bit patterns whose low 16 bits are zero (= bf16 in the high half)
-__device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
-  h = __builtin_bit_cast(unsigned, v) & 0xffff0000u;
-  const float r1 = v - __builtin_bit_cast(float, h);
-  m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-  const float r2 = r1 - __builtin_bit_cast(float, m);
-  l = __builtin_bit_cast(unsigned, r2);
+// v = h + m + l EXACTLY, each piece a bf16: h = bf16(v), m = bf16(v - h), l = v - h - m with round-to-nearest-even conversions
+// (v_cvt_pk_bf16_f32, two elements per instruction).  v - h is exact (at most 16 significant bits: h and v share their leading
+// bits), so is (v - h) - m, and what is left after two 8-bit roundings of a 24-bit number has at most 8 significant bits: the
+// last conversion changes nothing.  Rounding instead of truncating halves every piece: |m| <= 2^-8 |v|, |l| <= 2^-16 |v| - it makes
+// no difference to the nine-product sum (exact either way) and bounds what the six-product form leaves out (m l' + l m' + l l')
+// by 2^-23 |v w|.  Returns the three pieces of (v0, v1) as packed bf16 pairs, element order v0, v1.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& hp, unsigned& mp, unsigned& lp) {
+  hp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{v0, v1}), bf16x2));
+  const float r0 = v0 - __builtin_bit_cast(float, hp << 16), r1 = v1 - __builtin_bit_cast(float, hp & 0xffff0000u);
+  mp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{r0, r1}), bf16x2));
+  const float l0 = r0 - __builtin_bit_cast(float, mp << 16), l1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
+  lp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{l0, l1}), bf16x2));
 }
-// the high halves of (b, a) as one register {a.hi16 | b.hi16 << 16}: element order a, b
-__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 template <int PB, int NPROD>
 __global__ __launch_bounds__(256, 2) void conv1x1_pw_split(PwsParams p) {
@@ -115,15 +120,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_split(PwsParams p) {
   // plane q: [pixel][4 slots of 16 bytes = 8 k each], slot ^= (pixel / 4) % 4; this thread's 4 k are half (chunk & 1) of slot chunk >> 1
   auto store_x1 = [&](int i, int stage) {
     const int px = prow + 8 * NW * i;
-    unsigned h[4], m[4], l[4];
-    split3(xreg[i].x, h[0], m[0], l[0]);
-    split3(xreg[i].y, h[1], m[1], l[1]);
-    split3(xreg[i].z, h[2], m[2], l[2]);
-    split3(xreg[i].w, h[3], m[3], l[3]);
+    unsigned h[2], m[2], l[2];
+    split3_pair(xreg[i].x, xreg[i].y, h[0], m[0], l[0]);
+    split3_pair(xreg[i].z, xreg[i].w, h[1], m[1], l[1]);
     unsigned char* at = smem + stage * STAGE + px * 64 + (((chunk >> 1) ^ ((px >> 2) & 3)) * 16) + (chunk & 1) * 8;
-    *reinterpret_cast<u32x2*>(at) = u32x2{pack_hi(h[0], h[1]), pack_hi(h[2], h[3])};
-    *reinterpret_cast<u32x2*>(at + PLANE) = u32x2{pack_hi(m[0], m[1]), pack_hi(m[2], m[3])};
-    *reinterpret_cast<u32x2*>(at + 2 * PLANE) = u32x2{pack_hi(l[0], l[1]), pack_hi(l[2], l[3])};
+    *reinterpret_cast<u32x2*>(at) = u32x2{h[0], h[1]};
+    *reinterpret_cast<u32x2*>(at + PLANE) = u32x2{m[0], m[1]};
+    *reinterpret_cast<u32x2*>(at + 2 * PLANE) = u32x2{l[0], l[1]};
   };
   auto store_x = [&](int stage) {
 #pragma unroll
@@ -281,8 +284,8 @@ __global__ void pws_pack_weights_kernel(const float* __restrict__ w, unsigned sh
     const int co = 32 * grp + 8 * ((lane & 15) >> 2) + 4 * cb + (lane & 3);
     const int ci = kt * SK + 8 * (lane >> 4) + e;
     unsigned h, m, l;
-    split3(w[(long)co * Cin + ci], h, m, l);
-    u[o] = (unsigned short)((q == 0 ? h : q == 1 ? m : l) >> 16);
+    split3_pair(w[(long)co * Cin + ci], 0.f, h, m, l);
+    u[o] = (unsigned short)((q == 0 ? h : q == 1 ? m : l) & 0xffffu);
   }
 }
 

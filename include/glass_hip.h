@@ -165,7 +165,7 @@ int glass_conv1x1_pointwise_nhwc(const glass_conv_desc* d, const float* x, const
  * in 9 x 16 instead of 8 x 32 matrix cycles per 32 input channels.  Same descriptor / epilogue as glass_conv1x1_pointwise_nhwc,
  * results equal to glass_conv2d_nhwc up to summation order.  `u_packed`: glass_pointwise_split_pack_weights lays W [Cout][Cin]
  * out as three bf16 planes in MFMA fragment order (glass_pointwise_split_weight_bytes = 6 Cout Cin bytes), once per layer.
- * `products`: 9 (the exact product; the model path) or 6 (without the three piece pairs below 2^-23 relative: measurement
+ * `products`: 9 (the exact product; the model path) or 6 (without the three piece pairs that together stay below 2^-23 relative: measurement
  * only).  Inputs must be finite (inf - inf in the split).                                                               */
 int glass_pointwise_split_supported(const glass_conv_desc* d);
 size_t glass_pointwise_split_weight_bytes(int Cout, int Cin);

@@ -53,7 +53,8 @@ for (N, H, W, Cin, Cout, st, has_res) in LAYERS:
     rng = float(ref.abs().max())
     out = {}
     for name, force in (("routed", None), ("pws9", "pws9"), ("pws6", "pws6")):
-        t = timeit(lambda: K.conv2d_nhwc(x, w, b, winograd=force, **kw))
+        rt = K.default_routing().replace(split=0) if force is None else None      # "routed": what the fp32-MFMA routing picks
+        t = timeit(lambda: K.conv2d_nhwc(x, w, b, winograd=force, routing=rt, **kw))
         path = K.last_conv_path()
         err = float((y.reshape(-1, Cout)[idx].double() - ref).abs().max()) / rng
         out[name] = (t, err, path)
