@@ -31,5 +31,6 @@ for (N, H, W, Cin, Cout, st, has_res) in [(8, 256, 256, 256, 256, 1, 1), (8, 64,
     y = torch.empty((N, Ho, Wo, Cout), device=dev)
     for force in (None, "pws9", "pws6"):
         quiet_leg(f"[{N},{H},{W},{Cin}]->{Cout} s{st} {force or 'fp32 MFMA (routed)'}",
-                  lambda: K.conv2d_nhwc(x, w, None, stride=st, relu=1, residual=res, res_mode=1 if has_res else 0, out=y, winograd=force),
+                  lambda: K.conv2d_nhwc(x, w, None, stride=st, relu=1, residual=res, res_mode=1 if has_res else 0, out=y, winograd=force,
+                                            routing=K.default_routing().replace(split=0) if force is None else None),
                   2.0 * N * Ho * Wo * Cin * Cout)
