@@ -27,6 +27,7 @@
 //
 // Arithmetic is lstm_step_kernel's, instruction for instruction (same MFMA operand order and accumulator pairing, same
 // gate functions): the two paths are bit-identical (tests/test_gpu_g_persistent_rnn.py).
+#include <atomic>
 #include <mutex>
 #include "recognition_common.h"
 
@@ -43,15 +44,32 @@ constexpr int PL_GRAN = PL_RB * PL_HD;        // granules per chain and parity
 constexpr unsigned PL_SPIN_LIMIT = 1u << 21;  // x (one sweep + s_sleep) ~ 2-4 s: far beyond any wait for a peer to be scheduled
 constexpr int PL_CTRL_BYTES = 256;
 
+// what a bounded wait reports to, and how long it waits
+struct PlGuard {
+  int* status;         // library-owned, sticky (glass_recurrence_status): bit 0 = an LSTM hand-off gave up, bit 1 = a decoder hand-off
+  int* call_status;    // caller-owned word of THIS call (may be null): the same bits - what the host checks at its next read-back
+  unsigned spin_limit; // sweeps a wavefront waits for a peer before it gives up (PL_SPIN_LIMIT; lowered by the test hook only)
+  int withhold;        // test hook: the workgroup that drew this start ticket never publishes (-1: none)
+};
+
 struct PlParams {
   const float* xg;
   const float* whh;
   float* out;
   unsigned long long* gran;
   unsigned* ctrl;      // [0] start tickets
-  int* status;         // library-owned, sticky: bit 0 = an LSTM hand-off gave up, bit 1 = a decoder hand-off gave up
+  PlGuard guard;
   int R, T, NG, nsets;
 };
+
+// a wavefront stops waiting for a hand-off: both status words get the bit, the wavefront skips every later wait
+__device__ __forceinline__ void give_up(const PlGuard& g, int bit, int lane, bool& dead) {
+  dead = true;
+  if (lane == 0) {
+    atomicOr(g.status, bit);
+    if (g.call_status) atomicOr(g.call_status, bit);
+  }
+}
 
 // workgroup barrier for LDS hand-offs only: waits for this wavefront's LDS operations, NOT for its global loads -
 // __syncthreads() drains vmcnt too, which would stall every step on the prefetches that are meant to stay in flight
@@ -64,7 +82,7 @@ __device__ __forceinline__ void sweep_issue(const gu64* src, int tid, unsigned l
 }
 // ... and take them: re-read until every tag is `epoch`, then the values go to LDS as the chain's h rows
 __device__ __forceinline__ void sweep_finish(const gu64* src, unsigned epoch, int tid, int lane, unsigned long long (&v)[8],
-                                             float (*hs)[PL_HD + 4], bool& dead, int* status, int bit) {
+                                             float (*hs)[PL_HD + 4], bool& dead, const PlGuard& guard, int bit) {
   unsigned spins = 0;
   for (;;) {
     bool ok = true;
@@ -72,10 +90,7 @@ __device__ __forceinline__ void sweep_finish(const gu64* src, unsigned epoch, in
     for (int j = 0; j < 8; ++j) ok &= (unsigned)(v[j] >> 32) == epoch;
     if (__all(ok) || dead) break;
     __builtin_amdgcn_s_sleep(2);
-    if (++spins > PL_SPIN_LIMIT) {          // wavefront-uniform
-      dead = true;
-      if (lane == 0) atomicOr(status, bit);
-    }
+    if (++spins > guard.spin_limit) give_up(guard, bit, lane, dead);          // wavefront-uniform
     sweep_issue(src, tid, v);
   }
 #pragma unroll
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(PL_THREADS) void lstm_persistent_kernel(PlParams p)
       if (s > 0) {
         const gu64* src = gp + ((s - 1) & 1) * PL_GRAN;
         if (NCH == 1 || (s == 1 && ci == 0)) sweep_issue(src, tid, v);       // (otherwise issued during the previous chain-step)
-        sweep_finish(src, (unsigned)s, tid, lane, v, hs, dead, p.status, 1);
+        sweep_finish(src, (unsigned)s, tid, lane, v, hs, dead, p.guard, 1);
         PL_STAMP(0)
         lds_barrier();
         PL_STAMP(1)
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(PL_THREADS) void lstm_persistent_kernel(PlParams p)
       const LstmCell cell = lstm_cell(x0 + g0, x1 + g1, x2 + g2, x3 + g3, c[ci]);
       c[ci] = cell.c;
       const float hn = valid ? cell.h : 0.f;
-      if (s + 1 < T)
+      if (s + 1 < T && (int)s_ticket != p.guard.withhold)
         __hip_atomic_store(gp + (s & 1) * PL_GRAN + pr * PL_HD + u, ((unsigned long long)(unsigned)(s + 1) << 32) | __float_as_uint(hn),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (valid) p.out[((long)rr * T + t) * (2 * PL_HD) + dir * PL_HD + u] = hn;
@@ -226,6 +241,25 @@ static int* recurrence_status_word() {
   return g_status[dev];
 }
 
+// test hook state (glass_recurrence_test_hook): read by the launch wrappers, process-wide
+static std::atomic<unsigned> g_spin_limit{PL_SPIN_LIMIT};
+static std::atomic<int> g_withhold{-1};
+
+static bool fill_guard(PlGuard& g, int* call_status) {
+  g.status = recurrence_status_word();
+  g.call_status = call_status;
+  g.spin_limit = g_spin_limit.load();
+  g.withhold = g_withhold.load();
+  return g.status != nullptr;
+}
+
+extern "C" int glass_recurrence_test_hook(int64_t spin_limit, int withhold_ticket) {
+  GLASS_CHECK_ARG(spin_limit <= (int64_t)PL_SPIN_LIMIT, "glass_recurrence_test_hook: spin_limit above the built-in bound");
+  g_spin_limit.store(spin_limit <= 0 ? PL_SPIN_LIMIT : (unsigned)spin_limit);
+  g_withhold.store(withhold_ticket < 0 ? -1 : withhold_ticket);
+  return GLASS_OK;
+}
+
 extern "C" int glass_recurrence_status(int* status_out, int reset) {
   GLASS_CHECK_ARG(status_out, "glass_recurrence_status: null pointer");
   int* w = recurrence_status_word();
@@ -243,8 +277,8 @@ extern "C" int64_t glass_bilstm_persistent_workspace_bytes(int R, int Hd) {
 }
 
 extern "C" int glass_bilstm_recurrence_persistent(const float* xg, const float* w_hh, float* out, int R, int T, int Hd,
-                                                  int dirs_per_workgroup, int groups_per_workgroup, void* workspace,
-                                                  int64_t workspace_bytes, glass_stream_t stream) {
+                                                  int dirs_per_workgroup, int groups_per_workgroup, int* call_status,
+                                                  void* workspace, int64_t workspace_bytes, glass_stream_t stream) {
   GLASS_CHECK_ARG(Hd == PL_HD, "glass_bilstm_recurrence_persistent: only Hd=256 is built (got %d)", Hd);
   if (R == 0) return GLASS_OK;
   GLASS_CHECK_ARG(xg && w_hh && out && T > 0 && workspace, "glass_bilstm_recurrence_persistent: bad args");
@@ -262,8 +296,7 @@ extern "C" int glass_bilstm_recurrence_persistent(const float* xg, const float* 
   p.nsets = cdiv(p.NG, ng) * (nd == 2 ? 1 : 2);
   p.ctrl = static_cast<unsigned*>(workspace);
   p.gran = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + PL_CTRL_BYTES);
-  p.status = recurrence_status_word();
-  if (!p.status) { glass_set_error("glass_bilstm_recurrence_persistent: no status word (hipMalloc failed)"); return GLASS_EHIP; }
+  if (!fill_guard(p.guard, call_status)) { glass_set_error("glass_bilstm_recurrence_persistent: no status word (hipMalloc failed)"); return GLASS_EHIP; }
   // every polled word (tickets, granule tags) is zero before every launch; tags count steps from 1
   hipError_t e = hipMemsetAsync(workspace, 0, (size_t)glass_bilstm_persistent_workspace_bytes(R, Hd), s);
   if (e != hipSuccess) { glass_set_error("glass_bilstm_recurrence_persistent: memset: %s", hipGetErrorString(e)); return GLASS_EHIP; }
@@ -312,7 +345,7 @@ struct PdParams {
   int R, T, C, max_len, nsets;
   float* out; int* pred;
   unsigned long long *hgran, *cgran, *sgran, *ygran, *lgran;   // per set: [parity][16 x 256] x 3, [parity][16], [parity][16 x 128]
-  unsigned* ctrl; int* status;
+  unsigned* ctrl; PlGuard guard;
 };
 
 __device__ __forceinline__ unsigned long long granule(unsigned epoch, float v) {
@@ -420,7 +453,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
       unsigned long long v[8];
       const gu64* src = hg + (i & 1) * PD_GRAN;
       sweep_issue(src, tid, v);
-      sweep_finish(src, (unsigned)i, tid, lane, v, hs, dead, p.status, 2);
+      sweep_finish(src, (unsigned)i, tid, lane, v, hs, dead, p.guard, 2);
     }
     lds_barrier();
     PD_STAMP(0)
@@ -443,7 +476,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
     PD_STAMP(1)
     // ---- publish this workgroup's rows of sEmbed(h_i) and its class slice of fc(h_i) for the 16 RoIs (threads 0-255)
     if (tid < PD_RB * PD_UB) {
-      if (i < L) {
+      if (i < L && (int)s_ticket != p.guard.withhold) {
         const float sv = ((spart[0][pr][pu] + spart[1][pr][pu]) + (spart[2][pr][pu] + spart[3][pr][pu])) + sbias;
         __hip_atomic_store(sg + (i & 1) * PD_GRAN + pr * PD_D + u, granule((unsigned)(i + 1), sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -461,7 +494,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
           sv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__all((unsigned)(sv >> 32) == (unsigned)(i + 1)) || dead) break;
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > PL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(p.status, 2); }
+          if (++spins > p.guard.spin_limit) give_up(p.guard, 2, lane, dead);
         }
         sproj[tid] = __uint_as_float((unsigned)sv);
       }
@@ -489,7 +522,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
             l1 = __hip_atomic_load(src + min(lane + 64, C - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all((unsigned)(l0 >> 32) == (unsigned)(i + 1) && (unsigned)(l1 >> 32) == (unsigned)(i + 1)) || dead) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > PL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(p.status, 2); }
+            if (++spins > p.guard.spin_limit) give_up(p.guard, 2, lane, dead);
           }
           vv[0] = lane < C ? (fcbs[lane] + __uint_as_float((unsigned)l0)) * p.temperature : -INFINITY;
           vv[1] = lane + 64 < C ? (fcbs[lane + 64] + __uint_as_float((unsigned)l1)) * p.temperature : -INFINITY;
@@ -568,7 +601,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
       unsigned long long v[8];
       const gu64* src = cg + (i & 1) * PD_GRAN;
       sweep_issue(src, tid, v);
-      sweep_finish(src, (unsigned)(i + 1), tid, lane, v, cs, dead, p.status, 2);
+      sweep_finish(src, (unsigned)(i + 1), tid, lane, v, cs, dead, p.guard, 2);
       PD_STAMP(5)
       // the symbols: thread (pr, pu) needs y of RoI pr for its row of the embedding table
       if (tid < PD_RB * PD_UB) {
@@ -578,7 +611,7 @@ __global__ __launch_bounds__(PD_THREADS) void decode_persistent_kernel(PdParams 
           yv = __hip_atomic_load(yg + (i & 1) * PD_RB + pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__all((unsigned)(yv >> 32) == (unsigned)(i + 1)) || dead) break;
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > PL_SPIN_LIMIT) { dead = true; if (lane == 0) atomicOr(p.status, 2); }
+          if (++spins > p.guard.spin_limit) give_up(p.guard, 2, lane, dead);
         }
         int y = (int)(unsigned)yv;
         y = min(max(y, 0), C - 1);
@@ -637,7 +670,8 @@ extern "C" int glass_decode_persistent_supported(int T, int D, int C, int max_le
 extern "C" int glass_attention_decode_persistent(const float* x, const float* xproj, const glass_decoder_weights* w,
                                                  const float* sW_rowmajor, const float* emb_gi, const int* roi_image, int R,
                                                  int num_images, int T, int D, int C, int max_len, int eos, float* out,
-                                                 int* pred_scratch, void* workspace, int64_t workspace_bytes, glass_stream_t stream) {
+                                                 int* pred_scratch, int* call_status, void* workspace, int64_t workspace_bytes,
+                                                 glass_stream_t stream) {
   GLASS_CHECK_ARG(glass_decode_persistent_supported(T, D, C, max_len),
                   "glass_attention_decode_persistent: needs D=256, T<=32, C<=128 (got D=%d T=%d C=%d)", D, T, C);
   if (R == 0) return GLASS_OK;
@@ -657,8 +691,7 @@ extern "C" int glass_attention_decode_persistent(const float* x, const float* xp
   p.sgran = p.cgran + (size_t)p.nsets * 2 * PD_GRAN;
   p.ygran = p.sgran + (size_t)p.nsets * 2 * PD_GRAN;
   p.lgran = p.ygran + (size_t)p.nsets * 2 * PD_RB;
-  p.status = recurrence_status_word();
-  if (!p.status) { glass_set_error("glass_attention_decode_persistent: no status word (hipMalloc failed)"); return GLASS_EHIP; }
+  if (!fill_guard(p.guard, call_status)) { glass_set_error("glass_attention_decode_persistent: no status word (hipMalloc failed)"); return GLASS_EHIP; }
   hipError_t e = hipMemsetAsync(workspace, 0, (size_t)glass_decode_persistent_workspace_bytes(R), s);
   if (e != hipSuccess) { glass_set_error("glass_attention_decode_persistent: memset: %s", hipGetErrorString(e)); return GLASS_EHIP; }
   hipLaunchKernelGGL(decode_persistent_kernel, dim3(p.nsets * PD_NS), dim3(PD_THREADS), 0, s, p);

@@ -29,7 +29,7 @@ EXPORTS = [
     "glass_preprocess_image", "glass_image_u8hwc_to_chw_resized", "glass_roi_align_rotated",
     "glass_rpn_workspace_bytes", "glass_rpn_topk_decode", "glass_rotated_nms_select", "glass_pairwise_iou_rotated", "glass_detections_finalize", "glass_postprocess_words", "glass_text_argmax", "glass_pack_word_records",
     "glass_box_decode", "glass_gc_attention_inplace", "glass_mean_over_h", "glass_bilstm_workspace_bytes", "glass_bilstm_recurrence",
-    "glass_bilstm_persistent_workspace_bytes", "glass_bilstm_recurrence_persistent", "glass_recurrence_status",
+    "glass_bilstm_persistent_workspace_bytes", "glass_bilstm_recurrence_persistent", "glass_recurrence_status", "glass_recurrence_test_hook",
     "glass_decode_persistent_supported", "glass_decode_persistent_workspace_bytes", "glass_attention_decode_persistent",
     "glass_decode_workspace_bytes", "glass_attention_decode", "glass_decode_step_workspace_bytes", "glass_attention_decode_step",
 ]
@@ -50,7 +50,7 @@ class GlassLibraryError(RuntimeError):
 DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 
 
-ABI_VERSION = 5      # what csrc/common.hip glass_abi_version() returns: bumped whenever include/glass_hip.h gains or changes an entry
+ABI_VERSION = 6      # what csrc/common.hip glass_abi_version() returns: bumped whenever include/glass_hip.h gains or changes an entry
 
 
 def sources() -> List[str]:

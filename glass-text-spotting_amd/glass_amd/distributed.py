@@ -192,10 +192,12 @@ def all_gather_records(local: torch.Tensor, group=None, rows: int = None) -> tor
         if local.shape[0] < rows:
             pad = torch.zeros((rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             local = torch.cat([local, pad], 0)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         if oversize is not None:
             raise ValueError(f"all_gather_records: {oversize} local records > rows={rows}")
         return local.unsqueeze(0)
+    # (a ONE-rank process group still runs the collective: that is how RCCL's all_gather is put through this code path on a
+    #  1-GPU box - bench.py GLASS_BENCH_RCCL_WORLD1, tests/test_gpu_h_sharded.py)
     world = dist.get_world_size(group)
     if rows is None:
         mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
@@ -363,7 +365,12 @@ def gpu_numa_cpus(dev_index: int) -> Tuple[Optional[int], List[int], str]:
     (single-node hosts report -1) or the device cannot be located."""
     try:
         pr = torch.cuda.get_device_properties(dev_index)
-        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}.0"
+        # a torch build without the pci_* attributes must NOT fabricate 0000:00:00.0 - that address exists in sysfs (the host
+        # bridge, usually NUMA node 0) and every rank would be pinned to node 0 while the report says "pinned" (ADVICE r5)
+        dom, bus, dv = (getattr(pr, n, None) for n in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if dom is None or bus is None or dv is None:
+            return None, [], "?"
+        bdf = f"{int(dom):04x}:{int(bus):02x}:{int(dv):02x}.0"
     except Exception:                                            # noqa: BLE001 - no device: nothing to pin to
         return None, [], "?"
     return _numa_cpus_of_pci(bdf) + (bdf,)

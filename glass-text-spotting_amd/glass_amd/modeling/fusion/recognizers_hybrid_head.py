@@ -71,6 +71,7 @@ class BatchedDetections:
         self.kept_index = None        # [N,K] int32: index into the image's proposal list each detection came from
         self.detected = None          # with override_boxes: the box head's own detections (this object holds the overrides)
         self.proposals = None         # (boxes [N,P,5], logits [N,P], counts [N]) of the RPN, set by the meta-arch
+        self.handoff = None           # ops.native.HandoffGuard of the recognizer call that produced `text` (until resolved)
         self.roi_start_host = [0]
         for c in self.counts_host[:-1]:
             self.roi_start_host.append(self.roi_start_host[-1] + c)
@@ -189,8 +190,9 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         return self.box_predictor.inference_batched(preds, prop_boxes, prop_counts, image_hw_dev)
 
     def recognizer_branch_batched(self, img_nhwc4: torch.Tensor, feats: Dict[str, torch.Tensor], boxes: torch.Tensor,
-                                  roi_image: torch.Tensor, num_images: int, return_intermediates: bool = False):
-        """boxes [R,5], roi_image int32 [R] -> pred_text_prob [R,26,97] (R > 0)."""
+                                  roi_image: torch.Tensor, num_images: int, return_intermediates: bool = False, guard=None):
+        """boxes [R,5], roi_image int32 [R] -> pred_text_prob [R,26,97] (R > 0).  `guard`: ops.native.HandoffGuard the caller
+        resolves at its next read-back (None: the recognizer head reads the hand-off status itself, synchronising)."""
         R = boxes.shape[0]
         p2, p3 = feats[self.recognizer_in_features[0]], feats[self.recognizer_in_features[1]]
         fus = self.recognizer_feature_fusion
@@ -212,7 +214,7 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         self._local_extractor_streams(crops, xcat)
         inter = {"xcat": xcat.clone(), "crops": crops} if return_intermediates else None
         fused = self.fusion_net.forward_interleaved(xcat)
-        probs = self.recognizer_head.forward_nhwc(fused, roi_image, num_images)
+        probs = self.recognizer_head.forward_nhwc(fused, roi_image, num_images, guard=guard)
         if return_intermediates:
             inter["fused"] = fused
             return probs, inter
@@ -305,7 +307,10 @@ class MaskRotatedRecognizerHybridHead(InferenceModule):
         else:
             boxes = torch.cat([det.boxes[n, :c] for n, c in enumerate(counts)], 0).contiguous()
             roi_image = K.upload(torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)), torch.int32, device)
-        det.text = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts))
+        # the one-launch recurrent kernels report a hand-off that gave up into det.handoff.status; the meta-arch reads it with
+        # the surviving counts (its next read-back) and, if set, replaces det.text by det.handoff.retry() - the step kernels
+        det.handoff = K.HandoffGuard(device)
+        det.text = self.recognizer_branch_batched(img_nhwc4, feats, boxes, roi_image, len(counts), guard=det.handoff)
         if self.mask_inference:
             det.masks = self.mask_branch_batched(feats, boxes, roi_image)
         return det

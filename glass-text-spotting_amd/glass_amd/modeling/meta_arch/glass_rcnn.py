@@ -141,6 +141,7 @@ class GeneralizedRCNN(InferenceModule):
             det.proposals = (t["pboxes"], t["plogits"], t["pcounts"])      # padded RPN output of this step (parity tests)
             if do_postprocess:
                 return (yield from self._postprocess_batched_g(det, batched_inputs, images.image_sizes))
+            yield from self._resolve_handoff_g(det)      # (no later read-back on this path: the status gets its own)
             self.last_batch = det                # convenience for the synchronous API only; pipelined callers use .batch
             out = StepOutput(det.to_instances())
             out.batch = det
@@ -156,6 +157,16 @@ class GeneralizedRCNN(InferenceModule):
     # small-box filter of GlassRCNN._postprocess; the stock d2 GeneralizedRCNN has none
     _filter_small = False
     _min_box_dim = 0.0
+
+    @staticmethod
+    def _resolve_handoff_g(det):
+        """the persistent recurrent kernels' fail-safe for callers WITHOUT a later read-back: read the recognizer call's
+        hand-off status now; if a wait gave up, det.text is re-computed on the step kernels (ops.native.HandoffGuard)"""
+        guard, det.handoff = getattr(det, "handoff", None), None
+        if guard is not None:
+            again = guard.resolve((yield ReadBack(guard.status))[0][0])
+            if again is not None:
+                det.text = again
 
     def _postprocess_batched(self, det, batched_inputs, image_sizes):
         return drive(self._postprocess_batched_g(det, batched_inputs, image_sizes))
@@ -178,12 +189,25 @@ class GeneralizedRCNN(InferenceModule):
         roi_start = K.upload(det.roi_start_host, torch.int32, dev) if (det.text is not None or det.masks is not None) else None
         ob, os_, oo, ot, oc = K.detections_finalize(det.boxes, det.scores, det.orient, det.text, det.counts_dev, roi_start,
                                                     scale_xy, out_hw, float(self._min_box_dim), self._filter_small)
+        guard, det.handoff = getattr(det, "handoff", None), None
         om = None
         if det.masks is not None:
             # the same ordered compaction for the mask rows (the kernel's "text" slot carries any per-RoI payload)
             _, _, _, om, _ = K.detections_finalize(det.boxes, det.scores, None, det.masks[:, 0].contiguous(), det.counts_dev,
                                                    roi_start, scale_xy, out_hw, float(self._min_box_dim), self._filter_small)
-        counts = (yield ReadBack(oc))[0].tolist()
+        if guard is None:
+            counts = (yield ReadBack(oc))[0].tolist()
+        else:
+            # the recognizer's hand-off status rides on the read-back of the surviving counts (no extra synchronisation); if a
+            # persistent kernel gave up a wait, the text rows are re-computed on the step kernels and finalized again
+            host = yield ReadBack(oc, guard.status)
+            counts = host[0].tolist()
+            again = guard.resolve(host[1][0])
+            if again is not None:
+                det.text = again
+                ob, os_, oo, ot, oc = K.detections_finalize(det.boxes, det.scores, det.orient, det.text, det.counts_dev, roi_start,
+                                                            scale_xy, out_hw, float(self._min_box_dim), self._filter_small)
+                counts = (yield ReadBack(oc))[0].tolist()
         post = BatchedDetections(ob, os_, oo, oc, counts, out_sizes)
         post.text = ot
         self.last_batch = post
@@ -246,8 +270,8 @@ class GlassRCNN(GeneralizedRCNN):
         # per-image index logic: take the list-wise path (reference order of operations) instead of the fused kernel
         if self.inflate_ratio or self.drop_overlapping_boxes:
             self.last_batch = None
+            yield from self._resolve_handoff_g(det)
             return self._postprocess(det.to_instances(), batched_inputs, image_sizes)
-            yield                                          # pragma: no cover (keeps this a generator)
         return (yield from super()._postprocess_batched_g(det, batched_inputs, image_sizes))
 
 

@@ -132,11 +132,18 @@ class ASTER_V2(InferenceModule):
         return p.to(dev_), s[:, 0].to(dev_)
 
     def forward(self, features: torch.Tensor, labels=None, roi_image: Optional[torch.Tensor] = None,
-                num_images: int = 1) -> torch.Tensor:
+                num_images: int = 1, rnn=None, status=None) -> torch.Tensor:
         """features [R,T,D] -> probabilities [R,max_word_len,num_classes].  `roi_image` (int32 [R],
         image id per RoI) scopes the reference's early break to one image's RoIs; default: one call =
-        one image, as in the reference."""
+        one image, as in the reference.  `rnn` / `status`: as in BiLSTMBlockV2.forward_nhwc; without a `status` word
+        (the reference's call surface) the hand-off status is read here and a give-up re-runs the decoder on the step kernels."""
         assert labels is None and not self.training, "inference only"
+        if status is None and rnn != "steps":
+            guard = K.HandoffGuard(features.device, owner=self)
+            out = self.forward(features, labels, roi_image, num_images, rnn=getattr(self, "rnn_override", None) or rnn, status=guard.status)
+            guard.retry = lambda: self.forward(features, labels, roi_image, num_images, rnn="steps")
+            again = guard.resolve(guard.status.item())
+            return out if again is None else again
         x = features.contiguous()
         R, T, D = x.shape
         if roi_image is None:
@@ -144,4 +151,4 @@ class ASTER_V2(InferenceModule):
             num_images = 1
         xproj = K.linear(x.view(R * T, D), self.w["xW"], self.w["xB"]).view(R, T, D)
         return K.attention_decode(x, xproj, self.w, roi_image, num_images, self.num_classes, self.max_word_len, 0,
-                                  mode=K.routing_of(self.w["xW"]).rnn)
+                                  mode=rnn if rnn is not None else K.routing_of(self.w["xW"]).rnn, status=status)

@@ -41,16 +41,25 @@ class BiLSTMBlockV2(InferenceModule):
             self.layers.append({"w_ih": conv_weight(w_ih, device), "b": dev(b, device), "w_hh": dev(w_hh, device),
                                 "lin_w": conv_weight(sd[q + "linear.weight"], device), "lin_b": dev(sd[q + "linear.bias"], device)})
 
-    def forward_nhwc(self, feats: torch.Tensor) -> torch.Tensor:
-        """feats [R,H,W,C] -> [R,W,C]."""
+    def forward_nhwc(self, feats: torch.Tensor, rnn=None, status=None) -> torch.Tensor:
+        """feats [R,H,W,C] -> [R,W,C].  `rnn`: overrides the weights' `Routing.rnn` ("steps": the fall-back of a hand-off that
+        gave up); `status`: this call's hand-off status word (ops.native.new_handoff_status) for the persistent kernel."""
         x = K.mean_over_h(feats)
         R, T, _ = x.shape
         for L in self.layers:
             xg = K.linear(x.view(R * T, -1), L["w_ih"], L["b"]).view(R, T, 2, 4 * self.hidden)
-            rec = K.bilstm_recurrence(xg, L["w_hh"], self.hidden, mode=K.routing_of(L["w_ih"]).rnn)
+            rec = K.bilstm_recurrence(xg, L["w_hh"], self.hidden, mode=rnn if rnn is not None else K.routing_of(L["w_ih"]).rnn,
+                                      status=status)
             x = K.linear(rec.view(R * T, -1), L["lin_w"], L["lin_b"]).view(R, T, -1)
         return x
 
     def forward(self, features: torch.Tensor) -> torch.Tensor:
+        """the reference's call surface (NCHW in): no later read-back to ride on, so the hand-off status is read here (one
+        small synchronising copy) and a give-up re-runs the layer stack on the step kernels"""
         from ..backbone.resnet_fpn import as_nhwc
-        return self.forward_nhwc(as_nhwc(features))
+        x = as_nhwc(features)
+        guard = K.HandoffGuard(x.device, owner=self)
+        out = self.forward_nhwc(x, rnn=getattr(self, "rnn_override", None), status=guard.status)
+        guard.retry = lambda: self.forward_nhwc(x, rnn="steps")
+        again = guard.resolve(guard.status.item())
+        return out if again is None else again

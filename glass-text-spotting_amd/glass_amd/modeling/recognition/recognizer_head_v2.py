@@ -39,11 +39,33 @@ class RecognizerRCNNHeadV3(InferenceModule):
         self.encoder.import_weights(sd, device, prefix + "encoder.")
         self.decoder.import_weights(sd, device, prefix + "decoder.")
 
-    def forward_nhwc(self, x: torch.Tensor, roi_image: torch.Tensor, num_images: int) -> torch.Tensor:
-        """x [R,8,32,256] fused features -> probabilities [R,26,97]."""
+    rnn_override = None       # "steps" once K.HandoffGuard.STICKY_AFTER hand-off give-ups were seen by this head
+    rnn_giveups = 0
+
+    def forward_nhwc(self, x: torch.Tensor, roi_image: torch.Tensor, num_images: int, guard=None) -> torch.Tensor:
+        """x [R,8,32,256] fused features -> probabilities [R,26,97].
+        `guard` (ops.native.HandoffGuard): the one-launch BiLSTM / decoder kernels report a hand-off that gave up into
+        `guard.status`, and `guard.retry` re-runs encoder + decoder of THIS call on the step kernels - the caller resolves the
+        guard at its next host read-back (GeneralizedRCNN._postprocess_batched_g: the surviving-count read).  Without a guard
+        the status is read here (one small synchronising copy): no path returns text from a dead hand-off."""
         f = self.backbone.forward_nhwc(x)
-        enc = self.encoder.forward_nhwc(f)
-        return self.decoder(enc, roi_image=roi_image, num_images=num_images)
+        own = guard is None
+        if own:
+            guard = K.HandoffGuard(x.device, owner=self)
+        elif guard.owner is None:
+            guard.owner = self
+
+        def run(rnn, status):
+            enc = self.encoder.forward_nhwc(f, rnn=rnn, status=status)
+            return self.decoder(enc, roi_image=roi_image, num_images=num_images, rnn=rnn, status=status)
+        if self.rnn_override == "steps":
+            return run("steps", None)
+        out = run(None, guard.status)
+        guard.retry = lambda: run("steps", None)
+        if own:
+            again = guard.resolve(guard.status.item())
+            return out if again is None else again
+        return out
 
     def forward(self, x: torch.Tensor, instances: List[Instances]):
         assert not self.training, "inference only"

@@ -418,13 +418,21 @@ int glass_bilstm_recurrence(const float* xg, const float* w_hh, float* out, int 
  * dirs_per_workgroup / groups_per_workgroup: how many independent chains a workgroup interleaves - (2,1) (0,0 = default:
  * both directions of one RoI group, 8 workgroups per 16 RoIs), (2,2) or (1,1).  `workspace` (16-byte aligned, >=
  * glass_bilstm_persistent_workspace_bytes()) is zeroed by the call.  Every in-kernel wait is bounded; a wait that gave up
- * raises bit 0 of the device's sticky status word, read (after a device synchronise) with glass_recurrence_status
- * (bit 1: glass_attention_decode_persistent).                                                                  */
+ * (the outputs of that call are then undefined) raises bit 0 (bit 1: glass_attention_decode_persistent) of
+ *   - `call_status`, a caller-owned device int of THIS call (may be null; the caller zeroes it and reads it back with whatever
+ *     it reads back next on the stream - the product path does, and re-runs the call on glass_bilstm_recurrence when it is set:
+ *     glass_amd/modeling/fusion/recognizers_hybrid_head.py), and
+ *   - the device's sticky status word, read (after a device synchronise) with glass_recurrence_status - a diagnostic.       */
 int64_t glass_bilstm_persistent_workspace_bytes(int R, int Hd);
 int glass_bilstm_recurrence_persistent(const float* xg, const float* w_hh, float* out, int R, int T, int Hd,
-                                       int dirs_per_workgroup, int groups_per_workgroup, void* workspace,
+                                       int dirs_per_workgroup, int groups_per_workgroup, int* call_status, void* workspace,
                                        int64_t workspace_bytes, glass_stream_t stream);
 int glass_recurrence_status(int* status_out, int reset);
+/* Test hook for the bounded waits of the two persistent recurrent kernels (process-wide, applies to launches issued after the
+ * call): `spin_limit` sweeps before a wavefront gives up (<= 0: the built-in bound, ~2-4 s), `withhold_ticket` >= 0: the
+ * workgroup that draws that start ticket never publishes its slice, so its peers' waits give up (-1: off).  The product never
+ * calls it; tests/test_gpu_g_persistent_rnn.py uses it to force the fall-back of the product path.                        */
+int glass_recurrence_test_hook(int64_t spin_limit, int withhold_ticket);
 
 /* ------------------------------------------------------------------ attention decoder
  * Greedy additive-attention GRU decoder (AttentionRecognitionHead.sample,
@@ -455,13 +463,13 @@ int glass_attention_decode(const float* x, const float* xproj, const glass_decod
  * built once at load: sW_rowmajor [D][D] (sEmbed.weight as stored by torch; `w->sW` is not read) and emb_gi [C][3D] =
  * tgt_embedding.weight @ W_ih[:, :D]^T + b_ih (the embedding half of the GRU input needs no arithmetic per step; `w->emb`,
  * `w->b_ih` are not read).  Needs D == 256, T <= 32, C <= 128 (glass_decode_persistent_supported); `workspace` (16-byte
- * aligned, >= glass_decode_persistent_workspace_bytes) is zeroed by the call.  Bounded waits: bit 1 of
- * glass_recurrence_status.  Two launches (decoder, early-break mask).                                              */
+ * aligned, >= glass_decode_persistent_workspace_bytes) is zeroed by the call.  Bounded waits: bit 1 of `call_status` (may be
+ * null) and of glass_recurrence_status, as for glass_bilstm_recurrence_persistent.  Two launches (decoder, early-break mask). */
 int glass_decode_persistent_supported(int T, int D, int C, int max_len);
 int64_t glass_decode_persistent_workspace_bytes(int R);
 int glass_attention_decode_persistent(const float* x, const float* xproj, const glass_decoder_weights* w, const float* sW_rowmajor,
                                       const float* emb_gi, const int* roi_image, int R, int num_images, int T, int D, int C,
-                                      int max_len, int eos, float* out, int* pred_scratch, void* workspace,
+                                      int max_len, int eos, float* out, int* pred_scratch, int* call_status, void* workspace,
                                       int64_t workspace_bytes, glass_stream_t stream);
 
 /* ONE step of the same decoder for a search driven by the caller - `output, state, alpha = self.decoder(x, state, y_prev)`

@@ -34,7 +34,7 @@ for R in (32, 256):
         rc = L.glass_attention_decode_persistent(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(xp.data_ptr()), ctypes.byref(w),
                                                  ctypes.c_void_p(dec.w["sW_rm"].data_ptr()), ctypes.c_void_p(dec.w["emb_gi"].data_ptr()),
                                                  ctypes.c_void_p(ri.data_ptr()), R, int(ri.max()) + 1, 32, 256, 97, 26, 0, ctypes.c_void_p(out.data_ptr()),
-                                                 ctypes.c_void_p(pred.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ctypes.c_int64(nb), ctypes.c_void_p(K.stream_handle()))
+                                                 ctypes.c_void_p(pred.data_ptr()), ctypes.c_void_p(None), ctypes.c_void_p(ws.data_ptr()), ctypes.c_int64(nb), ctypes.c_void_p(K.stream_handle()))
         assert rc == 0
         torch.cuda.synchronize()
     st = ws[64:64 + 192].view(torch.int64).cpu().tolist()

@@ -17,7 +17,7 @@ for R in (32, 256):
         ws = torch.zeros((nb,), dtype=torch.uint8, device=dev)
         for _ in range(3):
             rc = L.glass_bilstm_recurrence_persistent(ctypes.c_void_p(xg.data_ptr()), ctypes.c_void_p(whh.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                                      R, T, 256, nd, ng, ctypes.c_void_p(ws.data_ptr()), ctypes.c_int64(nb), ctypes.c_void_p(stream_handle()))
+                                                      R, T, 256, nd, ng, ctypes.c_void_p(None), ctypes.c_void_p(ws.data_ptr()), ctypes.c_int64(nb), ctypes.c_void_p(stream_handle()))
             assert rc == 0
             torch.cuda.synchronize()
         st = ws[64:64 + 48].view(torch.int64).cpu().tolist()

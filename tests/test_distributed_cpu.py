@@ -407,6 +407,14 @@ def test_numa_pinning_helpers(tmp_path):
     assert D._numa_cpus_of_pci("0000:1a:00.0", str(sysfs)) == (None, [])
     assert D._numa_cpus_of_pci("0000:ff:00.0", str(sysfs)) == (None, [])
     before = os.sched_getaffinity(0)
+    # a torch build whose device properties lack the pci_* attributes must not be mapped to 0000:00:00.0
+    import types
+    from unittest import mock
+    with mock.patch.object(D.torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(name="gpu")):
+        assert D.gpu_numa_cpus(0) == (None, [], "?")
+    with mock.patch.object(D.torch.cuda, "get_device_properties",
+                           lambda i: types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x0d, pci_device_id=0)):
+        assert D.gpu_numa_cpus(0)[2] == "0000:0d:00.0"
     rep = D.pin_to_gpu_numa_node(0)                      # no GPU here: nothing to pin to
     assert rep["pinned"] is False and os.sched_getaffinity(0) == before and rep["cpus_after"] == len(before)
     pre = D.preflight_report(8, "nccl")

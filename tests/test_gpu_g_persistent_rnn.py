@@ -192,3 +192,138 @@ def test_persistent_decoder_honours_the_temperature():
     c = K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode=(1, 1)).cpu().numpy()
     live = b.sum(-1) > 0
     assert float(np.abs(a - b)[live].max()) < 1e-5 and float(np.abs(a - c).max()) > 1e-4
+
+
+# ------------------------------------------------------------------------------------------- fail-safe
+# A persistent kernel whose bounded wait gives up returns garbage.  The product path must never hand that out: every
+# persistent launch gets a per-call status word, the owner of the step's next read-back resolves it (ops.native.HandoffGuard)
+# and re-runs the recognizer's encoder / decoder on the step kernels.  glass_recurrence_test_hook forces the give-up: the
+# workgroup that draws start ticket 0 never publishes, and its peers give up after a few thousand sweeps instead of ~2-4 s.
+
+class _forced_giveup:
+    def __init__(self, spin_limit=3000, withhold=0):
+        self.args = (spin_limit, withhold)
+
+    def __enter__(self):
+        from glass_amd.ops import native as K
+        K.recurrence_test_hook(*self.args)
+
+    def __exit__(self, *a):
+        from glass_amd.ops import native as K
+        K.recurrence_test_hook(0, -1)
+        torch.cuda.synchronize()
+        K.recurrence_status(reset=True)
+
+
+def test_forced_giveup_raises_the_call_status_and_the_sticky_word():
+    """kernel level: the hook makes both persistent kernels give up; bit 0 (BiLSTM) / bit 1 (decoder) land in the caller's
+    per-call word AND in the device's sticky word; a launch without the hook leaves both at 0 and is correct again"""
+    from glass_amd.ops import native as K
+    xg, whh = _lstm_inputs(40, 32, 5)
+    ref = K.bilstm_recurrence(xg, whh, 256, mode="steps")
+    dec, _ = _decoder()
+    x = torch.randn((40, 32, 256), generator=torch.Generator().manual_seed(9)).to(_dev())
+    ri = torch.zeros((40,), dtype=torch.int32, device=_dev())
+    xproj = K.linear(x.view(40 * 32, 256), dec.w["xW"], dec.w["xB"]).view(40, 32, 256)
+    K.recurrence_status(reset=True)
+    with _forced_giveup():
+        st = K.new_handoff_status(_dev())
+        K.bilstm_recurrence(xg, whh, 256, mode=(1, 1), status=st)
+        assert int(st.item()) == 1
+        assert K.recurrence_status(reset=True) == 1
+        st2 = K.new_handoff_status(_dev())
+        K.attention_decode(x, xproj, dec.w, ri, 1, dec.num_classes, dec.max_word_len, 0, mode=(1, 1), status=st2)
+        assert int(st2.item()) == 2
+        assert K.recurrence_status(reset=True) == 2
+        # a launch WITHOUT a per-call word still reports into the sticky one
+        K.bilstm_recurrence(xg, whh, 256, mode=(2, 1))
+        assert K.recurrence_status(reset=True) == 1
+    st = K.new_handoff_status(_dev())
+    got = K.bilstm_recurrence(xg, whh, 256, mode=(1, 1), status=st)
+    assert int(st.item()) == 0 and K.recurrence_status() == 0 and torch.equal(got, ref)
+
+
+def test_reference_surface_modules_fall_back_to_the_step_kernels_on_a_giveup(golden_dir):
+    """`encoder(x)` / `decoder(x)` - the reference's call surface, no later read-back - under a forced give-up still return the
+    reference goldens (bilstm_encoder.npz, attention_decoder.npz): the status is read inside the call and the step kernels
+    re-run it (reference recognizer_encoder.py:118-144, prediction_aster.py:63-99)."""
+    import os
+    import numpy as np
+    import glass_amd
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.ops import native as K
+    from glass_amd.utils.synth import make_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_glass_cfg(os.path.join(root, "configs", "glass_icdar15_mi355x.yaml"))
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(make_state_dict(1234))
+    enc, dec = m.roi_heads.recognizer_head.encoder, m.roi_heads.recognizer_head.decoder
+    ge = np.load(os.path.join(golden_dir, "bilstm_encoder.npz"))
+    gd = np.load(os.path.join(golden_dir, "attention_decoder.npz"))
+    n0 = K.handoff_giveups()
+    with _forced_giveup():
+        y = enc(torch.from_numpy(ge["x"]).to(_dev())).cpu().numpy()
+        p = dec(torch.from_numpy(gd["x"]).to(_dev())).cpu().numpy()
+    assert K.handoff_giveups() == n0 + 2, "both calls must have gone through the fall-back"
+    assert float(np.abs(y - ge["y"]).max()) < 1e-4
+    assert float(np.abs(p - gd["y"]).max()) < 1e-4
+    # and without the hook the persistent path itself is taken (no further give-up is counted)
+    y2 = enc(torch.from_numpy(ge["x"]).to(_dev())).cpu().numpy()
+    assert K.handoff_giveups() == n0 + 2 and float(np.abs(y2 - ge["y"]).max()) < 1e-4
+
+
+def test_model_inference_survives_a_dead_handoff_and_goes_sticky_after_three():
+    """product level: `model.inference` (with and without its post-process read-back), the pipelined step generator and
+    `GlassRunner` under a forced give-up return EXACTLY what a model routed to the step kernels returns; the fall-back is
+    counted, and after HandoffGuard.STICKY_AFTER give-ups the head stays on the step kernels (no further give-ups)."""
+    import os
+    import glass_amd
+    from glass_amd.config import get_glass_cfg
+    from glass_amd.ops import native as K
+    from glass_amd.utils.pipeline import run_pipelined
+    from glass_amd.utils.synth import make_boxes, make_image, make_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_glass_cfg(os.path.join(root, "configs", "glass_icdar15_mi355x.yaml"), ["MODEL.DEVICE", "cuda:0"])
+    sd = make_state_dict(1234)
+    H, W, B, R = 160, 224, 2, 20                     # 40 RoIs: three 16-RoI groups, the last one ragged
+    imgs = [make_image(70 + i, H, W).permute(2, 0, 1).float().contiguous().cuda() for i in range(B)]
+    boxes = [(make_boxes(70 + i, R, H, W) * torch.tensor([1, 1, 0.3, 0.5, 1.0])).cuda() for i in range(B)]
+    inputs = [{"image": im} for im in imgs]
+
+    os.environ["GLASS_RNN"] = "steps"
+    try:
+        m_steps = glass_amd.build_model(cfg)
+    finally:
+        del os.environ["GLASS_RNN"]
+    m_steps.load_state_dict(sd)
+    assert m_steps.routing.rnn == "steps"
+    ref_raw = m_steps.inference(inputs, do_postprocess=False, override_boxes=boxes).batch.text.clone()
+    ref_out = m_steps.inference(inputs, override_boxes=boxes)
+    ref_post = ref_out.batch.text.clone()
+
+    m = glass_amd.build_model(cfg)
+    m.load_state_dict(sd)
+    assert m.routing.rnn == (1, 1)
+    head = m.roi_heads.recognizer_head
+    # sanity: untouched, the persistent path differs from the step kernels only by summation order and raises nothing
+    n0 = K.handoff_giveups()
+    ok = m.inference(inputs, do_postprocess=False, override_boxes=boxes).batch.text
+    assert K.handoff_giveups() == n0 and float((ok - ref_raw).abs().max()) < 1e-4
+    with _forced_giveup():
+        got_raw = m.inference(inputs, do_postprocess=False, override_boxes=boxes).batch.text.clone()       # own status read-back
+        assert K.handoff_giveups() == n0 + 1 and head.rnn_override is None
+        assert torch.equal(got_raw, ref_raw), "the fall-back must return the step kernels' result bit for bit"
+        got = m.inference(inputs, override_boxes=boxes)                                                      # rides on the count read-back
+        assert K.handoff_giveups() == n0 + 2 and head.rnn_override is None
+        assert torch.equal(got.batch.text, ref_post)
+        assert [len(a["instances"]) for a in got] == [len(a["instances"]) for a in ref_out]
+        piped = run_pipelined([(lambda: m.inference_g(inputs, override_boxes=boxes)) for _ in range(2)], depth=2, device=_dev())
+        torch.cuda.synchronize()
+        assert all(torch.equal(p.batch.text, ref_post) for p in piped)
+        # third + fourth give-up seen: the head is now pinned to the step kernels ...
+        assert head.rnn_override == "steps" and head.rnn_giveups >= K.HandoffGuard.STICKY_AFTER
+        n1 = K.handoff_giveups()
+        again = m.inference(inputs, override_boxes=boxes)
+        # ... so the hook (still armed) finds no persistent launch to break
+        assert K.handoff_giveups() == n1 and torch.equal(again.batch.text, ref_post)
+    assert K.recurrence_status() == 0
