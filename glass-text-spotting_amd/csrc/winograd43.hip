@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tpi = p.TH * p.TW;
-  unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
-  if constexpr (ABL == 4) stamp0 = __builtin_amdgcn_s_memtime();
+  unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0, real0 = 0;
+  if constexpr (ABL == 4) { stamp0 = __builtin_amdgcn_s_memtime(); real0 = __builtin_amdgcn_s_memrealtime(); }
 
   __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)p.u_bytes, 0x00020000);
@@ -393,10 +393,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
 #endif
   if constexpr (ABL == 4) {
     __builtin_amdgcn_s_waitcnt(0);
-    const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp3 = __builtin_amdgcn_s_memtime(), real3 = __builtin_amdgcn_s_memrealtime();
     if (p.dbg != nullptr && tid == 0) {
-      unsigned long long* o = p.dbg + (long)blockIdx.x * 4;
-      o[0] = stamp0; o[1] = stamp1; o[2] = stamp2; o[3] = stamp3;
+      // + the block's life on the 100 MHz counter every CU shares, and WHERE it ran (HW_REG_HW_ID = 4: cu_id [11:8], sh_id
+      // [12], se_id [15:13]; HW_REG_XCC_ID = 20): the gap accounting groups blocks by CU (scripts/exp_w43_gap.py)
+      unsigned long long* o = p.dbg + (long)blockIdx.x * 8;
+      o[0] = stamp0; o[1] = stamp1; o[2] = stamp2; o[3] = stamp3; o[4] = real0; o[5] = real3;
+      o[6] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+      o[7] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
   }
 }
@@ -524,7 +528,7 @@ static int wino43_launch(const glass_conv_desc* d, const float* x, const float* 
             : abl == 4 ? conv3x3_wino43_f32<4, 1, 4, 32> : conv3x3_wino43_f32<0, 1, 4, 32>;
   static unsigned long long* dbg_dev = nullptr;
   if (abl == 4) {
-    if (!dbg_dev) (void)hipMalloc(&dbg_dev, 4L * 8 * 65536);
+    if (!dbg_dev) (void)hipMalloc(&dbg_dev, 8L * 8 * 65536);
     p.dbg = nblk <= 65536 ? dbg_dev : nullptr;
   }
   static int attr_rc_w = -1, attr_rc_n = -1;
@@ -539,21 +543,28 @@ static int wino43_launch(const glass_conv_desc* d, const float* x, const float* 
   GLASS_CHECK_LAUNCH("glass_conv3x3_winograd43_nhwc");
   if (abl == 4 && p.dbg) {      // instrumented build: print the phase times of a few workgroups (drains the stream)
     static int printed = 0;
-    if (printed++ < 4) {
+    if (printed++ < (getenv("GLASS_W43_DBG_DUMP") ? 256 : 4)) {
       (void)hipStreamSynchronize((hipStream_t)stream);
-      std::vector<unsigned long long> h(4 * nblk);
+      std::vector<unsigned long long> h(8 * nblk);
       (void)hipMemcpy(h.data(), dbg_dev, h.size() * 8, hipMemcpyDeviceToHost);
-      unsigned long long t_min = ~0ull, t_max = 0;
-      double pro = 0, loop = 0, epi = 0;
+      unsigned long long t_min = ~0ull, t_max = 0, r_min = ~0ull, r_max = 0;
+      double pro = 0, loop = 0, epi = 0, life = 0;
       for (long b = 0; b < nblk; ++b) {
-        t_min = h[4 * b] < t_min ? h[4 * b] : t_min; t_max = h[4 * b + 3] > t_max ? h[4 * b + 3] : t_max;
-        pro += (double)(h[4 * b + 1] - h[4 * b]); loop += (double)(h[4 * b + 2] - h[4 * b + 1]); epi += (double)(h[4 * b + 3] - h[4 * b + 2]);
+        t_min = h[8 * b] < t_min ? h[8 * b] : t_min; t_max = h[8 * b + 3] > t_max ? h[8 * b + 3] : t_max;
+        r_min = h[8 * b + 4] < r_min ? h[8 * b + 4] : r_min; r_max = h[8 * b + 5] > r_max ? h[8 * b + 5] : r_max;
+        pro += (double)(h[8 * b + 1] - h[8 * b]); loop += (double)(h[8 * b + 2] - h[8 * b + 1]); epi += (double)(h[8 * b + 3] - h[8 * b + 2]);
+        life += (double)(h[8 * b + 5] - h[8 * b + 4]);
       }
-      fprintf(stderr, "[w43 dbg] blocks %ld nk %d: mean cycles prologue %.0f  k-loop %.0f (%.0f / k-tile)  epilogue %.0f | kernel span %llu (s_memtime ticks)\n",
-              nblk, p.nk, pro / nblk, loop / nblk, loop / nblk / p.nk, epi / nblk, t_max - t_min);
-      for (long b = 0; b < 3 && b < nblk; ++b)
-        fprintf(stderr, "[w43 dbg]   block %ld: start %llu  +%llu  +%llu  +%llu\n", b, h[4 * b] - t_min, h[4 * b + 1] - h[4 * b],
-                h[4 * b + 2] - h[4 * b + 1], h[4 * b + 3] - h[4 * b + 2]);
+      fprintf(stderr, "[w43 dbg] blocks %ld nk %d: mean s_memtime ticks prologue %.0f  k-loop %.0f (%.0f / k-tile)  epilogue %.0f | block life %.2f us, kernel span %.2f us "
+              "(s_memrealtime) = %llu ticks -> s_memtime at %.1f MHz\n",
+              nblk, p.nk, pro / nblk, loop / nblk, loop / nblk / p.nk, epi / nblk, life / nblk / 100.0, (double)(r_max - r_min) / 100.0, t_max - t_min,
+              (double)(t_max - t_min) / ((double)(r_max - r_min) / 100.0));
+      if (const char* path = getenv("GLASS_W43_DBG_DUMP")) {      // raw per-block records for scripts/exp_w43_gap.py
+        if (FILE* f = fopen(path, "ab")) {
+          const long hdr[4] = {nblk, p.nk, p.tiles_n, wide ? 1 : 0};
+          fwrite(hdr, sizeof(long), 4, f); fwrite(h.data(), 8, h.size(), f); fclose(f);
+        }
+      }
     }
   }
   return GLASS_OK;

@@ -9,6 +9,8 @@ LAYERS = [("fpn_out2 256@256 B8", 8, 256, 256, 256, 256), ("local l3 256@16x33 R
           ("fusion 512->256@8x32 R256", 256, 8, 32, 512, 256), ("local l2 128@32 R256", 256, 32, 32, 128, 128),
           ("local l1 64@64 R256", 256, 64, 64, 64, 64), ("res2.conv2 64@256 B8", 8, 256, 256, 64, 64),
           ("local l1.0 32->64@64 R256", 256, 64, 64, 32, 64)]
+if os.environ.get("W43_LAYERS"):            # e.g. W43_LAYERS=0,5: only those rows (PMC passes of one shape)
+    LAYERS = [LAYERS[int(i)] for i in os.environ["W43_LAYERS"].split(",")]
 for name, N, H, W, Cin, Cout in LAYERS:
     x = torch.randn((N, H, W, Cin), device=dev)
     w = K.prepare_conv_weights(torch.randn((Cout, 3, 3, Cin), device=dev) * 0.05, "all")     # packed once, like a loaded model's layer
