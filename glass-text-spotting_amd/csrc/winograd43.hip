@@ -42,6 +42,10 @@ namespace {
 //          waves share every weight fragment through the L1, V keeps its 72 KiB per stage with half the channels)
 constexpr int WINO43_LDS_BYTES = 2 * 36 * 16 * 32 * 4;      // V: 2 stages x 36 xi x (16 WT tiles) x KT channels = 144 KiB for both shapes
 constexpr int RING = 4;                       // weight-fragment ring slots (groups in flight = RING - 1)
+#ifndef GLASS_W43_VACC_XI
+#define GLASS_W43_VACC_XI 32
+#endif
+constexpr int VACC_XI = GLASS_W43_VACC_XI;    // xi >= VACC_XI accumulate in VGPRs (inline-asm MFMA); 36 = none (the round-5 code)
 constexpr unsigned INV = 0x40000000u;         // "invalid" part of a split offset: any sum containing it is >= 1 GiB
 
 __device__ __forceinline__ float comp4(const f32x4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
@@ -199,14 +203,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   const int vt = 16 * wt + vj;                // this lane's tile within the block
   const int vswz = (vt / RPW) % SLOTS;
   const float* vb[2] = {smem + vt * K4 + ((0 * 4 + kg) ^ vswz) * 4, smem + vt * K4 + (((HALVES - 1) * 4 + kg) ^ vswz) * 4};
-  const unsigned a_voff = (unsigned)lane * 16u;
+  // packed U: [tile_n][kt][xi][wc][half][cb] chunks of 1 KiB (64 lanes x float4); group u = HALVES xi + half.
+  // Address = wave part (lane, wc: one VGPR, set once) + (kt, xi) part (ONE scalar add per xi: the 2 HALVES chunks of an xi are
+  // contiguous, <= 3 KiB apart) + (half, cb) part as the instruction's 12-bit immediate - round 6: the loop carried one
+  // s_add_i32 per weight load (146 per k-tile, an issue slot each beside the MFMAs); now 36.
+  const unsigned a_voff = (unsigned)lane * 16u + (unsigned)wc * (HALVES * 2 * 1024);
   f32x4 aq[RING][2];                          // weight fragments: [ring slot = group % RING][cb]
   f32x4 vq[2];                                // V fragments: [group & 1]
-  // packed U: [tile_n][kt][xi][wc][half][cb] chunks of 1 KiB (64 lanes x float4); group u = HALVES xi + half
   auto load_a1 = [&](int kt, int u, int cb) {
     const int xi = u / HALVES, h = u % HALVES;
-    const int base = ABL == 1 ? (h * 2 + cb) * 1024 : (((((tile_n * p.nk + kt) * 36 + xi) * WC + wc) * HALVES + h) * 2 + cb) * 1024;
-    aq[u % RING][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, base, 0));
+#ifdef GLASS_W43_R5_ADDR     // the round-5 form (A/B builds only): the whole chunk offset in the scalar operand
+    const int sbase = ABL == 1 ? (h * 2 + cb) * 1024 : ((tile_n * p.nk + kt) * 36 + xi) * (WC * HALVES * 2 * 1024) + (h * 2 + cb) * 1024;
+    aq[u % RING][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, sbase, 0));
+#else
+    const int sbase = ABL == 1 ? 0 : ((tile_n * p.nk + kt) * 36 + xi) * (WC * HALVES * 2 * 1024);
+    aq[u % RING][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff + (unsigned)((h * 2 + cb) * 1024), sbase, 0));
+#endif
   };
   auto read_v = [&](int stage, int u) {
     vq[u & 1] = *reinterpret_cast<const f32x4*>(vb[u % HALVES] + stage * V4_FLOATS + (u / HALVES) * (T4 * K4));
@@ -258,13 +270,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        acc[xi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(aq[u % RING][cb], s), comp4(vq[u & 1], s), acc[xi][cb], 0, 0, 0);
+        // 72 accumulators of 4 registers = 288 > the 256 AGPRs: hipcc selects the AGPR form for every builtin MFMA of a
+        // 512-register kernel and shuttled the 8 accumulators that do not fit through scratch AGPRs around their MFMAs
+        // (40 v_accvgpr_write + 40 v_accvgpr_read + 12 x `s_nop 8..9` for the results, per k-tile and wave).  The MFMAs of
+        // the last four xi name their VGPR accumulator themselves (round 6): same instruction, C / D in VGPRs.
+        if constexpr (xi >= VACC_XI) {
+          f32x4 c = acc[xi][cb];                   // (asm operands cannot name a captured variable; the copies fold away)
+          const float af = comp4(aq[u % RING][cb], s), bf = comp4(vq[u & 1], s);
+          asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(af), "v"(bf));
+          acc[xi][cb] = c;
+        } else {
+          acc[xi][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(aq[u % RING][cb], s), comp4(vq[u & 1], s), acc[xi][cb], 0, 0, 0);
+        }
       });
       __builtin_amdgcn_sched_barrier(0);
     });
     __syncthreads();     // V[cur] fully read, V[cur^1] fully written
   }
 
+  // (the inline-asm MFMAs are invisible to the compiler's hazard recognizer: a VALU read of their VGPR results needs the matrix
+  //  pipe drained - 8 passes + margin.  The loop ends with a barrier and ~40 address instructions precede the first read; these
+  //  wait states make the distance explicit instead of incidental.)
+  if constexpr (VACC_XI < 36) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   if constexpr (ABL == 4) stamp2 = __builtin_amdgcn_s_memtime();
   // ---- epilogue: Y = At M A in registers; lane = (tile 16 wt + vj, channels n0 + 32 wc + 16 cb + 4 kg + e) ----
   // 32-bit buffer addressing with split offsets (row part + column part; an invalid part = 2^30 makes the sum out of

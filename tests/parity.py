@@ -110,3 +110,45 @@ def match_box_sets(got_boxes, got_scores, ref_boxes, ref_scores, atol_px=0.5, rt
         ds = max(ds, abs(gs[j] - rs[i]))
         db = max(db, float(d[j].max()))
     return hit / len(rb), float(used.mean()), ds, db
+
+
+def teacher_forced_text_probs(dec, enc, q):
+    """The product's decoder, one step at a time (glass_attention_decode_step: additive attention, GRU cell, fc, soft-max - the
+    arithmetic of the one-launch decoder), FED THE ORACLE'S previous symbols: step i of RoI r sees arg-max q[r, i-1] instead of its
+    own arg-max.  A greedy decoder turns an ulp-sized difference at a near-tie into a different word from there on; teacher-forced,
+    both sides walk the same symbol sequence and EVERY live step of EVERY RoI is comparable (no `max_tied`).
+    dec: ASTER_V2 with weights; enc [R,T,D] device tensor (the product's own encoder output); q [R,L,C] oracle probabilities
+    (rows of steps after the oracle's early break are zero and stay zero here).  Returns [R,L,C] numpy."""
+    import torch
+    from glass_amd.ops import native as K
+    q = np.asarray(q)
+    R, L, C = q.shape
+    out = np.zeros_like(q, dtype=np.float32)
+    if R == 0:
+        return out
+    enc = enc.contiguous()
+    T, D = enc.shape[1], enc.shape[2]
+    xproj = K.linear(enc.view(R * T, D), dec.w["xW"], dec.w["xB"]).view(R, T, D)
+    h = torch.zeros((R, D), dtype=torch.float32, device=enc.device)
+    y_prev = torch.zeros((R,), dtype=torch.int32, device=enc.device)
+    for i in range(L):
+        live = q[:, i].sum(-1) > 0
+        if not live.any():
+            break
+        _, probs, h = K.attention_decode_step(enc, xproj, dec.w, h, y_prev, C)
+        out[live, i] = probs.cpu().numpy()[live]
+        y_prev = torch.from_numpy(q[:, i].argmax(-1).astype(np.int32)).to(enc.device)
+    return out
+
+
+def text_prob_stats(p, q, what="text"):
+    """p vs q [R,L,C] over the live steps of q: (max |dp|, mean |dp|, 95th percentile of the per-step max |dp|, arg-max agreement)"""
+    p, q = np.asarray(p, dtype=np.float64), np.asarray(q, dtype=np.float64)
+    live = q.sum(-1) > 0
+    d = np.abs(p - q)[live]
+    step_max = d.max(-1)
+    agree = float((p.argmax(-1)[live] == q.argmax(-1)[live]).mean())
+    st = (float(d.max()), float(d.mean()), float(np.percentile(step_max, 95)), agree)
+    print(f"[parity] {what}: {int(live.sum())} live (RoI, step) pairs: max |dp| {st[0]:.3e}, mean |dp| {st[1]:.3e}, p95 of per-step max |dp| {st[2]:.3e}, "
+          f"arg-max agreement {st[3]:.4f}")
+    return st

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 import torch
 
-from parity import TOL, assert_detections_close, assert_same_box_set as _assert_same_box_set, assert_text_prob_close, maxdiff
+from parity import (TOL, assert_detections_close, assert_same_box_set as _assert_same_box_set, assert_text_prob_close, maxdiff,
+                    teacher_forced_text_probs, text_prob_stats)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -348,19 +349,46 @@ def test_fp16_modes_match_their_emulating_oracle_small(sd, prec):
         ref = O.glass_inference(sd, imgs, cfg, injected_boxes=boxes)
     res = m.inference([{"image": im.cuda()} for im in imgs], do_postprocess=False, override_boxes=[b.cuda() for b in boxes])
     det = res.batch
+    # every step of every RoI: the product's decoder fed the emulating oracle's symbols (no near-tie cut)
+    flat = torch.cat(boxes).contiguous().cuda()
+    ri = torch.tensor([0] * 6 + [1] * 6, dtype=torch.int32, device="cuda:0")
+    enc = _encoder_output(m, [{"image": im.cuda()} for im in imgs], flat, ri, 2)
+    qq = np.concatenate([r["pred_text_prob"].numpy() for r in ref], 0)
+    tf = teacher_forced_text_probs(m.roi_heads.recognizer_head.decoder, enc, qq)
+    mx, mean, _, agree = text_prob_stats(tf, qq, f"{prec} small batch, teacher-forced vs the emulating oracle")
+    # measured (round 6, 312 live steps): fp16 max 2.9e-3 / mean 9.1e-6 / agreement 1.0; fp16s 2.3e-3 / 1.3e-5 / 1.0
+    assert mx < 6e-3 and mean < 5e-5 and agree > 0.99
     for n, r in enumerate(ref):
         _compare_reduced(det, n, r, f"{prec} image {n}")
-        # greedy decoding under fp16 noise: steps whose top-2 gap is below 1e-2 may legitimately pick the other character
-        # (random weights give flat distributions: most RoIs hit such a step somewhere), RoIs are compared up to it
-        # (measured 8e-4 ... 2.0e-3; `max_tied=1.0`: with random weights the distributions are flat and most RoIs meet a
-        #  near-tie at some step - the teacher-forced stage test above is the one with the tight bounds)
-        assert_text_prob_close(res[n].pred_text_prob.cpu().numpy(), r["pred_text_prob"].numpy(), tol=4e-3, tie_eps=1e-2,
-                               what=f"{prec} image {n} text (6 injected boxes)", max_tied=1.0)
+        # free-running greedy decoding under fp16 noise: steps whose top-2 gap is below 1e-2 may legitimately pick the other
+        # character; RoIs are compared up to their first such step, and the share of RoIs that have one is the ORACLE's own
+        # property (random weights give flat distributions), asserted at what the oracle says instead of a blanket 1.0
+        q = r["pred_text_prob"].numpy()
+        srt = np.sort(q, axis=-1)
+        tied = float(((((srt[..., -1] - srt[..., -2]) < 1e-2) & (q.sum(-1) > 0)).any(1)).mean())
+        assert_text_prob_close(res[n].pred_text_prob.cpu().numpy(), q, tol=4e-3, tie_eps=1e-2,
+                               what=f"{prec} image {n} text (6 injected boxes, free-running)", max_tied=min(1.0, tied + 1e-9))
+
+
+def _encoder_output(m, inputs, boxes_flat, roi_image, n_images):
+    """the product's own decoder input for these boxes: pyramid -> poolers -> local extractor -> fusion -> CNN -> BiLSTM"""
+    il = m.preprocess_image(inputs)
+    feats = m.backbone.forward_nhwc(il.nhwc4)
+    _, inter = m.roi_heads.recognizer_branch_batched(il.nhwc4, feats, boxes_flat, roi_image, n_images, return_intermediates=True)
+    head = m.roi_heads.recognizer_head
+    return head.encoder.forward_nhwc(head.backbone.forward_nhwc(inter["fused"]))
 
 
 def test_config4_fp16_storage_full_shape_vs_emulating_oracle(sd):
     """BASELINE configs[4] in its stated precision: one 1000 x 1333 image of the TextOCR shape (orientation head off),
-    100 injected RoIs, fp16 STORAGE on the conv path, against the oracle emulating exactly that arithmetic."""
+    100 injected RoIs, fp16 STORAGE on the conv path.  Three comparisons, each with an ASSERTED bound:
+      (a) TEACHER-FORCED against the oracle emulating exactly that arithmetic: the product's decoder fed the oracle's previous
+          symbols - every live step of every RoI compared, no near-tie cut (`max_tied`);
+      (b) TEACHER-FORCED against the FP32 oracle - the reference's arithmetic; the reference has no fp16 path, so the 1e-3
+          north-star bound does not apply to this mode and THIS is its stated distance: arg-max agreement, mean and 95th
+          percentile of |dp|, at the values measured (DESIGN.md section 4);
+      (c) free-running (what the mode ships) against the emulating oracle, RoIs cut at their first near-tie as before - now
+          with the measured share of cut RoIs asserted instead of 1.0 - and proposals / detections as sets."""
     import glass_amd
     from glass_amd.utils.synth import make_boxes, make_image
     from oracle import glass_cpu as O
@@ -371,18 +399,38 @@ def test_config4_fp16_storage_full_shape_vs_emulating_oracle(sd):
     H, W, R = 1000, 1333, 100
     img = make_image(61, H, W).permute(2, 0, 1).float().contiguous()
     boxes = [make_boxes(61, R, H, W)]
-    res = m.inference([{"image": img.cuda()}], do_postprocess=False, override_boxes=[boxes[0].cuda()])
+    inputs = [{"image": img.cuda()}]
+    res = m.inference(inputs, do_postprocess=False, override_boxes=[boxes[0].cuda()])
     with O.emulate("fp16s"):
         ref = O.glass_inference(sd2, [img], cfg, injected_boxes=boxes)[0]
+    ref32 = O.glass_inference(sd2, [img], cfg, injected_boxes=boxes)[0]["pred_text_prob"].numpy()
     det = res.batch
     p, q = det.text.cpu().numpy(), ref["pred_text_prob"].numpy()
-    assert p.shape == q.shape == (R, 26, 97)
-    assert_text_prob_close(p, q, tol=8e-3, tie_eps=1e-2, what="configs[4] fp16 storage, 1000x1333, 100 RoIs, text", max_tied=1.0)   # measured 5.5e-3
-    # context: the same outputs against the FP32 oracle (what round 1 could only compare with) are further away
-    ref32 = O.glass_inference(sd2, [img], cfg, injected_boxes=boxes)[0]["pred_text_prob"].numpy()
-    live = (q.sum(-1) > 0) & (ref32.sum(-1) > 0)
-    print(f"[parity] configs[4] fp16 storage: mean |dp| vs emulating oracle {np.abs(p - q)[live].mean():.3e}, vs fp32 oracle {np.abs(p - ref32)[live].mean():.3e}")
+    assert p.shape == q.shape == ref32.shape == (R, 26, 97)
+    enc = _encoder_output(m, inputs, boxes[0].cuda().contiguous(), torch.zeros((R,), dtype=torch.int32, device="cuda:0"), 1)
+    dec = m.roi_heads.recognizer_head.decoder
+    # (a) every step of every RoI against the emulating oracle
+    tf = teacher_forced_text_probs(dec, enc, q)
+    mx, mean, p95, agree = text_prob_stats(tf, q, "configs[4] fp16 storage, teacher-forced vs the emulating oracle")
+    assert mx < FP16S_TF_EMU_MAX and mean < FP16S_TF_EMU_MEAN and agree > FP16S_TF_EMU_AGREE
+    # (b) ... and against the fp32 oracle (the reference's arithmetic)
+    tf32 = teacher_forced_text_probs(dec, enc, ref32)
+    mx, mean, p95, agree = text_prob_stats(tf32, ref32, "configs[4] fp16 storage, teacher-forced vs the FP32 oracle")
+    assert mean < FP16S_TF_F32_MEAN and p95 < FP16S_TF_F32_P95 and mx < FP16S_TF_F32_MAX and agree > FP16S_TF_F32_AGREE
+    # (c) free-running
+    srt = np.sort(q, axis=-1)
+    tied = float(((((srt[..., -1] - srt[..., -2]) < 1e-2) & (q.sum(-1) > 0)).any(1)).mean())
+    print(f"[parity] configs[4] fp16 storage: share of RoIs whose oracle meets a near-tie (< 1e-2) at some step: {tied:.2f}")
+    assert_text_prob_close(p, q, tol=8e-3, tie_eps=1e-2, what="configs[4] fp16 storage, 1000x1333, 100 RoIs, text (free-running)",
+                           max_tied=min(1.0, tied + 0.05))
     _compare_reduced(det, 0, ref, "configs[4] fp16 storage 1000x1333")
+
+
+# measured on MI355X (round 6, 2600 live (RoI, step) pairs; `pytest -s` prints the values next to these bounds; bounds = ~2-3 x):
+#   vs the emulating oracle: max |dp| 5.5e-3, mean 1.5e-5, p95 of the per-step max 1.5e-3, arg-max agreement 0.9992
+#   vs the FP32 oracle:      max |dp| 6.2e-3, mean 2.5e-5, p95 2.4e-3, arg-max agreement 0.9965 (9 of 2600 steps read another character)
+FP16S_TF_EMU_MAX, FP16S_TF_EMU_MEAN, FP16S_TF_EMU_AGREE = 1.2e-2, 5e-5, 0.995
+FP16S_TF_F32_MAX, FP16S_TF_F32_MEAN, FP16S_TF_F32_P95, FP16S_TF_F32_AGREE = 1.5e-2, 8e-5, 5e-3, 0.99
 
 
 def _fp16_ulps(got, ref):
@@ -465,4 +513,9 @@ def test_fp16s_stages_teacher_forced_ulp_histograms(sd):
     print(f"[fp16s teacher-forced] recognition branch, max |d| / range: {r}, character probabilities max |dp| {dp:.2e}")
     # measured (round 3): crops 5.9e-6, global 5.0e-4, local 1.2e-3, fused 8.3e-5 of the range; probabilities 2.6e-4
     assert r["crops"] < 1e-5 and r["global"] < 1e-3 and r["local"] < 2.5e-3 and r["fused"] < 5e-4
-    assert_text_prob_close(probs.cpu().numpy(), probs_ref.numpy(), tol=1e-3, tie_eps=1e-3, what="fp16s teacher-forced text", max_tied=1.0)
+    # the decoder too is teacher-forced (fed the oracle's symbols): every live step of every RoI, no near-tie cut
+    head = m.roi_heads.recognizer_head
+    enc = head.encoder.forward_nhwc(head.backbone.forward_nhwc(got["fused"]))
+    tf = teacher_forced_text_probs(head.decoder, enc, probs_ref.numpy())
+    mx, mean, _, agree = text_prob_stats(tf, probs_ref.numpy(), "fp16s teacher-forced pyramid AND decoder vs the emulating oracle")
+    assert mx < 1e-3 and mean < 1e-5 and agree > 0.99          # measured (round 6, 260 live steps): 2.8e-4 / 1.9e-6 / 1.0
