@@ -3,10 +3,12 @@
 // F(2x2,3x3) (winograd.hip) issues 16 multiplies per 2x2 output tile = 4 per output pixel and channel pair; F(4x4,3x3)
 // issues 36 per 4x4 tile = 2.25 (1.78x fewer again, 4x fewer than the direct convolution), reads 36 instead of 64
 // input values per 16 outputs and streams 2.25x the weight bytes.  fp32 accuracy is the price of the larger
-// transform: with the usual points (0, +-1, +-2) the error is 1.5e-5 of the output range on a 256-channel layer;
-// this kernel uses the points (0, 1, -1, 1/2, -2, inf), measured at 4.7e-6 (fp64 reference; tests/test_gpu_f_ops.py
-// holds the kernel to 2e-5 of the range), at the cost of a transform without the even/odd symmetry (16 instead of
-// ~12 operations per 6-point transform).
+// transform: with the usual points (0, +-1, +-2) the error is 1.3e-5 of the output range on a 256-channel layer.
+// Rounds 2-5 used the asymmetric points (0, 1, -1, 1/2, -2, inf): 4.8e-6, at the cost of a transform without the
+// even / odd symmetry (16 operations per 6-point transform).  Round 6: the points (0, +-3/4, +-3/2, inf) - the best pair of a
+// scan over +-a, +-b in eighths (fp32 emulation of this pipeline against fp64, 256 channels: 2.9e-6; +-1, +-2 is the same
+// set scaled by 4/3 and 4.5x worse) - are symmetric, so a transform is 12 fused multiply-adds (even part + / - odd part) AND
+// more accurate; every constant is dyadic, i.e. exact in fp32 (tests/test_gpu_f_ops.py holds the kernel to 2e-5 of the range).
 //
 //   Y(4x4) = At [ sum_c (G g G^t) . (Bt d B) ] A,   36 independent GEMMs  M_xi[cout][tile] = sum_c U_xi[cout][c] V_xi[c][tile]
 //
@@ -20,12 +22,12 @@
 //   * per k-tile: thread (tile, channel pair) fetches its raw 6x6 patch with 36 bounds-checked buffer_load_dwordx2
 //     (offset = row part + column part, an invalid part is 2^30 so that the sum is out of range: padding and ragged
 //     tiles are the hardware's zero fill; 12 offset registers instead of 36), applies Bt d B in place (12 six-point
-//     transforms of 16 fma/add per channel) and writes the 36 transformed pairs to LDS V[xi][tile][32], XOR-swizzled
+//     transforms of 12 fma per channel) and writes the 36 transformed pairs to LDS V[xi][tile][32], XOR-swizzled
 //     so that the MFMA-side ds_read_b128 (one per 8 MFMAs, feeding 4 k-steps x 2 channel blocks) is conflict free.
 //   * weights never touch LDS: U = G g G^t is pre-packed (glass_winograd43_pack_weights) in MFMA A-fragment order,
 //     each wave streams its own 1 KiB fragments L2 -> registers through a 4-slot ring, three groups ahead.
 //   * 576 MFMAs (18.4 K cycles) per wave and k-tile against 144 weight loads + 72 LDS reads + 36 patch loads + 36 LDS
-//     writes + ~390 VALU, all metered between the MFMAs (the source order IS the issue order, pinned with
+//     writes + ~300 VALU (round 6: 1367 instructions per k-tile, 1656 in round 5), all metered between the MFMAs (the source order IS the issue order, pinned with
 //     sched_barrier like the F(2x2) kernels); V is double buffered, one barrier per k-tile.
 #include "wino_common.h"
 #include <vector>
@@ -50,48 +52,53 @@ constexpr unsigned INV = 0x40000000u;         // "invalid" part of a split offse
 
 __device__ __forceinline__ float comp4(const f32x4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
-// six-point input transform (rows of Bt for the points 0, 1, -1, 1/2, -2, inf), one scalar channel:
-//   o0 =  d0 - 3/2 d1 - 2 d2 + 3/2 d3 + d4          o3 = -2 d1 - d2 + 2 d3 + d4
-//   o1 = -d1 + 1/2 d2 + 5/2 d3 + d4                 o4 = 1/2 d1 - d2 - 1/2 d3 + d4
-//   o2 =  d1 - 5/2 d2 + 1/2 d3 + d4                 o5 = d1 - 3/2 d2 - 2 d3 + 3/2 d4 + d5
+// Cook-Toom F(4,3) on the points p = (0, a, -a, b, -b, inf), a = 3/4, b = 3/2.  M(x) = x (x^2 - a^2)(x^2 - b^2);
+//   Bt row of p  = coefficients of M(x) / (x - p) (monic quartic; row inf = M itself),
+//   G  row of p  = (1, p, p^2) / prod_{q != p} (p - q)   (row inf = (0, 0, 1)),
+//   At[k][p]     = p^k, k = 0..3                          (column inf = (0, 0, 0, 1)).
+constexpr float WA = 0.75f, WB = 1.5f;
+constexpr float WA2 = WA * WA, WB2 = WB * WB, WS2 = WA2 + WB2, WP2 = WA2 * WB2, WA3 = WA2 * WA, WB3 = WB2 * WB;   // all exact
+
+// six-point input transform, one scalar channel (12 fma: even part +- odd part for each symmetric pair):
+//   o0 = a^2 b^2 d0 - (a^2 + b^2) d2 + d4                      o5 = a^2 b^2 d1 - (a^2 + b^2) d3 + d5
+//   o1, o2 = (d4 - b^2 d2) +- a (d3 - b^2 d1)                  o3, o4 = (d4 - a^2 d2) +- b (d3 - a^2 d1)
 struct Bt6 {
   float a, b, o0, o1, o2, o3, o4, o5;
   template <int S> __device__ __forceinline__ void step(float d0, float d1, float d2, float d3, float d4, float d5) {
-    if constexpr (S == 0) { a = d3 - d1; b = d4 - d2; }
-    if constexpr (S == 1) o0 = __builtin_fmaf(-2.f, d2, __builtin_fmaf(1.5f, a, d0 + d4));
-    if constexpr (S == 2) o1 = __builtin_fmaf(2.5f, d3, __builtin_fmaf(0.5f, d2, d4 - d1));
-    if constexpr (S == 3) o2 = __builtin_fmaf(0.5f, d3, __builtin_fmaf(-2.5f, d2, d4 + d1));
-    if constexpr (S == 4) o5 = __builtin_fmaf(-2.f, d3, __builtin_fmaf(1.5f, b, d1 + d5));
-    if constexpr (S == 5) { o3 = __builtin_fmaf(2.f, a, b); o4 = __builtin_fmaf(-0.5f, a, b); }
+    if constexpr (S == 0) { a = __builtin_fmaf(-WB2, d2, d4); b = __builtin_fmaf(-WB2, d1, d3); }
+    if constexpr (S == 1) o0 = __builtin_fmaf(WP2, d0, __builtin_fmaf(-WS2, d2, d4));
+    if constexpr (S == 2) { o1 = __builtin_fmaf(WA, b, a); o2 = __builtin_fmaf(-WA, b, a); }
+    if constexpr (S == 3) { a = __builtin_fmaf(-WA2, d2, d4); b = __builtin_fmaf(-WA2, d1, d3); }
+    if constexpr (S == 4) o5 = __builtin_fmaf(WP2, d1, __builtin_fmaf(-WS2, d3, d5));
+    if constexpr (S == 5) { o3 = __builtin_fmaf(WB, b, a); o4 = __builtin_fmaf(-WB, b, a); }
   }
 };
 
-// the same on a channel PAIR (packed fp32: v_pk_fma_f32 / v_pk_add_f32 process both channels in one issue slot; beside
-// the f32 MFMA, which occupies the vector ALU, halving the transform's instruction count is what counts)
+// the same on a channel PAIR (two scalar fma per operation: the library is built without packed-f32 instruction selection)
 struct Bt6p {
   f32x2 a, b, o0, o1, o2, o3, o4, o5;
   static __device__ __forceinline__ f32x2 fma2(float c, f32x2 x, f32x2 y) {
     return __builtin_elementwise_fma(f32x2{c, c}, x, y);
   }
   template <int S> __device__ __forceinline__ void step(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5) {
-    if constexpr (S == 0) { a = d3 - d1; b = d4 - d2; }
-    if constexpr (S == 1) o0 = fma2(-2.f, d2, fma2(1.5f, a, d0 + d4));
-    if constexpr (S == 2) o1 = fma2(2.5f, d3, fma2(0.5f, d2, d4 - d1));
-    if constexpr (S == 3) o2 = fma2(0.5f, d3, fma2(-2.5f, d2, d4 + d1));
-    if constexpr (S == 4) o5 = fma2(-2.f, d3, fma2(1.5f, b, d1 + d5));
-    if constexpr (S == 5) { o3 = fma2(2.f, a, b); o4 = fma2(-0.5f, a, b); }
+    if constexpr (S == 0) { a = fma2(-WB2, d2, d4); b = fma2(-WB2, d1, d3); }
+    if constexpr (S == 1) o0 = fma2(WP2, d0, fma2(-WS2, d2, d4));
+    if constexpr (S == 2) { o1 = fma2(WA, b, a); o2 = fma2(-WA, b, a); }
+    if constexpr (S == 3) { a = fma2(-WA2, d2, d4); b = fma2(-WA2, d1, d3); }
+    if constexpr (S == 4) o5 = fma2(WP2, d1, fma2(-WS2, d3, d5));
+    if constexpr (S == 5) { o3 = fma2(WB, b, a); o4 = fma2(-WB, b, a); }
   }
 };
 
-// four-point output transform (rows of At): y0 = m0+m1+m2+m3+m4, y1 = m1-m2+m3/2-2m4, y2 = m1+m2+m3/4+4m4,
-// y3 = m1-m2+m3/8-8m4+m5
+// four-point output transform (rows of At): y0 = m0 + (m1 + m2) + (m3 + m4), y1 = a (m1 - m2) + b (m3 - m4),
+// y2 = a^2 (m1 + m2) + b^2 (m3 + m4), y3 = a^3 (m1 - m2) + b^3 (m3 - m4) + m5
 __device__ __forceinline__ void at4(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1,
                                     float& y2, float& y3) {
-  const float s = m1 + m2, d = m1 - m2;
-  y0 = (m0 + s) + (m3 + m4);
-  y1 = __builtin_fmaf(-2.f, m4, __builtin_fmaf(0.5f, m3, d));
-  y2 = __builtin_fmaf(4.f, m4, __builtin_fmaf(0.25f, m3, s));
-  y3 = __builtin_fmaf(-8.f, m4, __builtin_fmaf(0.125f, m3, d)) + m5;
+  const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+  y0 = (m0 + s1) + s2;
+  y1 = __builtin_fmaf(WB, d2, WA * d1);
+  y2 = __builtin_fmaf(WB2, s2, WA2 * s1);
+  y3 = __builtin_fmaf(WB3, d2, __builtin_fmaf(WA3, d1, m5));
 }
 
 template <int ABL, int WT, int WC, int KT>   // ABL: timing ablations (GLASS_W43_ABL): 0 = product, 1 = weights from one hot chunk, 2 = no transform VALU, 3 = no patch loads, 4 = phase stamps
@@ -438,8 +445,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
 __global__ void wino43_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int WC, int KT) {
   const long total = 36L * Cout * Cin;
   const int nk = Cin / KT, halves = KT / 16;
-  const double G[6][3] = {{1.0, 0.0, 0.0}, {1.0 / 3, 1.0 / 3, 1.0 / 3}, {-1.0 / 3, 1.0 / 3, -1.0 / 3},
-                          {-16.0 / 15, -8.0 / 15, -4.0 / 15}, {1.0 / 15, -2.0 / 15, 4.0 / 15}, {0.0, 0.0, 1.0}};
+  // G rows of the points (0, a, -a, b, -b, inf): (1, p, p^2) / prod_{q != p} (p - q), in double
+  const double P[5] = {0.0, (double)WA, -(double)WA, (double)WB, -(double)WB};
+  double G[6][3];
+  for (int i = 0; i < 5; ++i) {
+    double f = 1.0;
+    for (int j = 0; j < 5; ++j) if (j != i) f *= P[i] - P[j];
+    G[i][0] = 1.0 / f; G[i][1] = P[i] / f; G[i][2] = P[i] * P[i] / f;
+  }
+  G[5][0] = 0.0; G[5][1] = 0.0; G[5][2] = 1.0;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
     long r = o;
     const int s = (int)(r & 3); r >>= 2;
