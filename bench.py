@@ -828,6 +828,11 @@ def main():
                                    "; GLASS_PW_SPLIT=6: the 1x1 layers DROP the three bf16-piece products below 2^-23 of each product "
                                    "(opt-in, measurement only: not the exact product, not the headline)"
                                    if getattr(model.routing, "split", 0) == 6 else ""))
+            # (the contract's `dtype: f32` line says where it is NOT the fp32 MFMA that multiplies)
+            line["config"]["matrix_pipes"] = ("3x3 / stems / implicit-GEMM layers: fp32 MFMA; eligible 1x1 layers: " +
+                                              {9: "bf16 MFMA on exact 3-way operand splits, all nine piece products (exact fp32 products)",
+                                               6: "bf16 MFMA on 3-way operand splits, SIX piece products (opt-in: not exact)"}.get(
+                                                  getattr(model.routing, "split", 0), "fp32 MFMA"))
         line["lib_source_sha16"] = source_sha16()
         # the persistent recurrent kernels' in-kernel waits are bounded: a hand-off that gave up raises a sticky status word
         # (bit 0 BiLSTM, bit 1 decoder) instead of hanging the GPU - 0 over the whole run or the line is not printed

@@ -139,7 +139,10 @@ class Routing:
       split       1x1 layers (Cin % 32 == 0, Cout % 128 == 0) on the bf16 matrix cores with EXACT fp32 products: each fp32
                   operand as three bf16 pieces, 9 = all nine piece products (the sum an fp32 fma chain accumulates, in another
                   order; the default), 6 = without the three products below 2^-23 (opt-in, measurement only), 0 = the fp32-MFMA
-                  kernels (GLASS_PW_SPLIT=0 | 6 | 9; csrc/pointwise_split.hip)
+                  kernels (GLASS_PW_SPLIT=0 | 6 | 9; csrc/pointwise_split.hip).  CAVEAT: +-inf / NaN operands (and |v| > 3.39e38)
+                  do not split (h = inf, v - h = NaN): one non-finite activation makes every output channel of its pixel NaN,
+                  where the fp32 kernels would propagate it only through the products it takes part in - same "non-finite in,
+                  non-finite out" contract, coarser; a forward pass on finite weights and images never produces one
       pooled_fusion  P2P3Fusion's two 1x1 convolutions AFTER the recognizer pooler (on the pooled bins) instead of on the whole
                   p2 / p3 maps - RoIAlign and the fusion are both linear (GLASS_POOLED_FUSION=0: whole-map fusion, then pool)"""
     __slots__ = ("precision", "winograd", "f43", "pw", "h16", "local_stem", "stem", "ragged", "pooled_fusion", "rnn", "splitk", "small_grid", "split")
