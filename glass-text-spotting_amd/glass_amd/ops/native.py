@@ -318,6 +318,7 @@ def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int, body: bool = False) ->
 
 
 NUM_CUS = 256
+_SPLIT_LONGK = os.environ.get("GLASS_SPLIT_LONGK", "1") != "0"      # (A/B switch of _use_split's long-k rule, read once)
 
 
 def _use_split(px: int, Cin: int, Cout: int) -> bool:
@@ -325,7 +326,13 @@ def _use_split(px: int, Cin: int, Cout: int) -> bool:
     per-workgroup weight stream is not amortised and the implicit-GEMM kernel's smaller tiles / split-K win: 1024 -> 256 at 64 x 64
     is 0.036 -> 0.050 ms) and, for the two-k-tile layers (Cin 64: prologue + epilogue per block are most of its life), only on big
     maps (64 -> 256 + residual: 0.93x at 8 x 256 x 256, 1.10x at 1 x 256 x 256) - profiles/r05_pw_split.txt, per-layer tables"""
-    return -(-px // 64) * (Cout // 128) >= 384 and (Cin >= 128 or px >= 262144)
+    blocks = -(-px // 64) * (Cout // 128)
+    if _SPLIT_LONGK and 192 <= blocks < 384 and Cin >= 512:
+        # round 6: layers that fill the chip only 0.75 - 1.5 times but run a LONG k-loop per block (>= 16 k-tiles: the weight stream of a
+        # block is amortised over its own k-loop, not over many blocks) - the box head's fc1 / fc2 at 800 rows, the FPN lateral on res5,
+        # the recurrent layers' input projections: 13 - 25 % faster than the implicit-GEMM kernel (scripts/exp_fc1_split.py)
+        return True
+    return blocks >= 384 and (Cin >= 128 or px >= 262144)
 
 
 def _small_grid_3x3(N: int, H: int, W: int, Cout: int, Cin: int, can_body: bool, f43_ok: bool):
