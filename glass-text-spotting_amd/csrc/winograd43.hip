@@ -47,6 +47,10 @@ constexpr int RING = 4;                       // weight-fragment ring slots (gro
 #ifndef GLASS_W43_VACC_XI
 #define GLASS_W43_VACC_XI 32
 #endif
+#ifndef GLASS_W43_STORE_AUX
+#define GLASS_W43_STORE_AUX 0
+#endif
+constexpr int W43_STORE_AUX = GLASS_W43_STORE_AUX;   // cache policy of the output stores (0 = default; 2 = nt: experiment, profiles/r06)
 constexpr int VACC_XI = GLASS_W43_VACC_XI;    // xi >= VACC_XI accumulate in VGPRs (inline-asm MFMA); 36 = none (the round-5 code)
 constexpr unsigned INV = 0x40000000u;         // "invalid" part of a split offset: any sum containing it is >= 1 GiB
 
@@ -297,8 +301,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
 
   // (the inline-asm MFMAs are invisible to the compiler's hazard recognizer: a VALU read of their VGPR results needs the matrix
   //  pipe drained - 8 passes + margin.  The loop ends with a barrier and ~40 address instructions precede the first read; these
-  //  wait states make the distance explicit instead of incidental.)
-  if constexpr (VACC_XI < 36) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  //  wait states make the distance explicit instead of incidental, and the empty statements tie every VGPR accumulator to them:
+  //  volatile asm statements keep their order, so no read of acc[VACC_XI..35] can be scheduled above the wait states.)
+  if constexpr (VACC_XI < 36) {
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = VACC_XI; i < 36; ++i) {
+      asm volatile("" : "+v"(acc[i][0]));
+      asm volatile("" : "+v"(acc[i][1]));
+    }
+  }
   if constexpr (ABL == 4) stamp2 = __builtin_amdgcn_s_memtime();
   // ---- epilogue: Y = At M A in registers; lane = (tile 16 wt + vj, channels n0 + 32 wc + 16 cb + 4 kg + e) ----
   // 32-bit buffer addressing with split offsets (row part + column part; an invalid part = 2^30 makes the sum out of
@@ -421,8 +433,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outs[0][a * 4 + b]), yr, yrow[a] + ycol[b], 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outs[1][a * 4 + b]), yr, yrow[a] + ycol[b], 64, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outs[0][a * 4 + b]), yr, yrow[a] + ycol[b], 0, W43_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outs[1][a * 4 + b]), yr, yrow[a] + ycol[b], 64, W43_STORE_AUX);
     }
 #endif
   if constexpr (ABL == 4) {
