@@ -20,3 +20,5 @@ for f in ("bench_rccl_world1","bench_2rank_gloo_on_1gpu"):
         d=json.load(open(f"gpurun_out/{f}.json")); print(f, round(d["value"],1), d["n_gpus"], d["comm"])
     except Exception as e: print(f,"FAILED",e)
 PY
+timeout 900 python bench.py --steps 1000 --warmup 5 --no-cpu-baseline --no-extras > $O/soak_1000steps_fp32.json 2> $O/soak.log
+python -c "import json; d=json.load(open('gpurun_out/soak_1000steps_fp32.json')); print('soak', round(d['value'],1), d.get('recurrence_handoff_status'), d.get('hbm_peak_reserved_gb'))"
