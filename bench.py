@@ -123,6 +123,9 @@ class ConvMeter:
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 1) // 2) * (y.shape[2] // 2) * 16 * cout * cin + \
                     2.0 * y.shape[0] * y.shape[1] * cout * 6 * cin
                 path = path[:-1]
+            elif path == "winograd43k":                 # the same kernel as k-slices + an ordered reduction (one image in flight; small levels):
+                ex = 2.0 * y.shape[0] * ((y.shape[1] + 3) // 4) * ((y.shape[2] + 3) // 4) * 36 * cout * cin      # same family, same executed count
+                path = "winograd43"
             elif path == "winograd43":                  # F(4x4,3x3): 36 MACs per (ceil(H/4) x ceil(W/4)) tile, channel pair
                 ex = 2.0 * y.shape[0] * ((y.shape[1] + 3) // 4) * ((y.shape[2] + 3) // 4) * 36 * cout * cin
             elif path == "pointwise_split":             # every fp32 product as 9 (or 6) exact bf16 piece products on the bf16 matrix cores

@@ -18,6 +18,7 @@
 //
 // blockIdx -> tile map is XCD-aware: hardware places block b on XCD b%8 (each XCD has its
 // own 4 MiB L2), so each XCD gets a contiguous run of tiles whose neighbours share A rows.
+#include "splitk_common.h"
 #include "common.h"
 #include <cstdlib>
 
@@ -645,42 +646,6 @@ static int conv_dispatch(const glass_conv_desc* d, const float* x, const float* 
 // implicit-GEMM kernel runs `splits` k-slices as grid.y (slice s = k-tiles [s nk / splits, (s+1) nk / splits) of the
 // (tap, channel) walk), slice s writes raw partial sums to workspace[s][M][Cout], and a second kernel adds them IN SLICE
 // ORDER (deterministic), then bias, ReLU, residual as the single-slice epilogue does, and writes y with its strides.
-namespace {
-struct SplitReduce {
-  const float* ws; const float* bias; const float* res; float* y;
-  long M; int Cout, splits, ldy, ycoff, ycs, ldr, relu, res_mode;
-};
-template <int V>   // V = 4: four channels per thread (unit channel stride, aligned), 1: one
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitReduce q) {
-  const long per = q.M * q.Cout;
-  const int cv = q.Cout / V;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per / V; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / cv;
-    const int c = (int)(i - m * cv) * V;
-    float a[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) a[e] = 0.f;
-    for (int s = 0; s < q.splits; ++s) {
-      if constexpr (V == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(q.ws + (long)s * per + m * q.Cout + c);
-        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-      } else {
-        a[0] += q.ws[(long)s * per + m * q.Cout + c];
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      float v = a[e] + (q.bias ? q.bias[c + e] : 0.f);
-      if (q.relu == 2) v = fmaxf(v, 0.f);
-      if (q.res_mode == 1) v += q.res[m * q.ldr + c + e];
-      if (q.relu == 1) v = fmaxf(v, 0.f);
-      a[e] = v;
-    }
-    if constexpr (V == 4) *reinterpret_cast<float4*>(q.y + m * q.ldy + q.ycoff + c) = make_float4(a[0], a[1], a[2], a[3]);
-    else q.y[m * q.ldy + q.ycoff + (long)c * q.ycs] = a[0];
-  }
-}
-}  // namespace
 
 extern "C" int64_t glass_conv2d_splitk_workspace_bytes(const glass_conv_desc* d, int splits) {
   if (!d) return 0;
@@ -730,15 +695,8 @@ extern "C" int glass_conv2d_nhwc_splitk(const glass_conv_desc* d, const float* x
   const int rc = d->Cout <= 32 ? launch_conv_impl<4, 1, 1, 1, 1, 4, 32>(p, s)          // 128 x 32 tiles (box predictors)
                                : launch_conv_impl<2, 2, 1, 1, 1, 8, 32>(p, s);         // 64 x 64 tiles, 8 workgroups per CU
   if (rc != GLASS_OK) return rc;
-  SplitReduce q;
-  q.ws = static_cast<const float*>(workspace); q.bias = bias; q.res = d->res_mode ? residual : nullptr; q.y = y;
-  q.M = M; q.Cout = d->Cout; q.splits = splits; q.ldy = d->ldy; q.ycoff = d->y_coff; q.ycs = d->y_cstride; q.ldr = d->ldr;
-  q.relu = d->relu; q.res_mode = d->res_mode;
-  const bool vec = d->Cout % 4 == 0 && d->y_cstride == 1 && d->ldy % 4 == 0 && d->y_coff % 4 == 0 && ((uintptr_t)y & 15) == 0;
-  const long n = M * d->Cout / (vec ? 4 : 1);
-  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, s, q);
-  else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, q);
+  launch_splitk_reduce(static_cast<const float*>(workspace), bias, residual, y, M, d->Cout, splits, d->ldy, d->y_coff, d->y_cstride, d->ldr,
+                       d->relu, d->res_mode, s);
   GLASS_CHECK_LAUNCH("glass_conv2d_nhwc_splitk");
   return GLASS_OK;
 }

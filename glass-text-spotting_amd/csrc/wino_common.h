@@ -19,7 +19,9 @@ struct WinoParams {
   const float* bias;
   const float* res;
   float* y;
-  int N, H, W, Cin, Cout, TH, TW, ntiles, nk;
+  int N, H, W, Cin, Cout, TH, TW, ntiles, nk;   // nk: k-tiles a workgroup walks (a k-SLICE of the layer when gridDim.y > 1)
+  int nkt;                         // k-tiles of the whole layer (stride of the packed weights); F(4x4) split-K: slice blockIdx.y starts at blockIdx.y * nk
+  long y_slice;                    // F(4x4) split-K: floats between the slices' partial outputs (y = workspace + blockIdx.y * y_slice)
   int ldx, ldy, ycoff, ldr, relu, res_mode;
   int tiles_m, tiles_n;
   unsigned x_bytes, u_bytes, y_bytes, r_bytes;

@@ -30,6 +30,7 @@
 //     writes + ~300 VALU (round 6: 1367 instructions per k-tile, 1656 in round 5), all metered between the MFMAs (the source order IS the issue order, pinned with
 //     sched_barrier like the F(2x2) kernels); V is double buffered, one barrier per k-tile.
 #include "wino_common.h"
+#include "splitk_common.h"
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -130,6 +131,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tpi = p.TH * p.TW;
+  // split-K (glass_conv3x3_winograd43_splitk_nhwc; gridDim.y slices of p.nk k-tiles each; one slice = the plain launch): this
+  // workgroup's first k-tile, as the channel offset of its patch loads and the k-tile index of its weight fragments
+  const int kt0 = blockIdx.y * p.nk;
+  const int xk0 = kt0 * (KT * 4), uk0 = tile_n * p.nkt + kt0;
   unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0, real0 = 0;
   if constexpr (ABL == 4) { stamp0 = __builtin_amdgcn_s_memtime(); real0 = __builtin_amdgcn_s_memrealtime(); }
 
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
     constexpr int i = decltype(i_)::value;
     if constexpr (ABL == 3) { if (kt > 1) return; }
     // (bit_cast the whole vector: __builtin_bit_cast of a single vector ELEMENT reads element 0 with this compiler)
-    dd[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, rowoff[i / 6] + coloff[i % 6], kt * (K4 * 4), 0));
+    dd[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, rowoff[i / 6] + coloff[i % 6], xk0 + kt * (K4 * 4), 0));
   };
   // V[stage][xi][tile][KT]: a row is 128 (64) bytes = a half (quarter) of the 64 banks; the 16-byte slot is XOR-ed with
   // (tile / rows-per-256-bytes) % slots so that the 16 tiles a ds_read_b128 service group touches hit 16 different slots.
@@ -224,10 +229,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   auto load_a1 = [&](int kt, int u, int cb) {
     const int xi = u / HALVES, h = u % HALVES;
 #ifdef GLASS_W43_R5_ADDR     // the round-5 form (A/B builds only): the whole chunk offset in the scalar operand
-    const int sbase = ABL == 1 ? (h * 2 + cb) * 1024 : ((tile_n * p.nk + kt) * 36 + xi) * (WC * HALVES * 2 * 1024) + (h * 2 + cb) * 1024;
+    const int sbase = ABL == 1 ? (h * 2 + cb) * 1024 : ((uk0 + kt) * 36 + xi) * (WC * HALVES * 2 * 1024) + (h * 2 + cb) * 1024;
     aq[u % RING][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff, sbase, 0));
 #else
-    const int sbase = ABL == 1 ? 0 : ((tile_n * p.nk + kt) * 36 + xi) * (WC * HALVES * 2 * 1024);
+    const int sbase = ABL == 1 ? 0 : ((uk0 + kt) * 36 + xi) * (WC * HALVES * 2 * 1024);
     aq[u % RING][cb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, a_voff + (unsigned)((h * 2 + cb) * 1024), sbase, 0));
 #endif
   };
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
   // ---- epilogue: Y = At M A in registers; lane = (tile 16 wt + vj, channels n0 + 32 wc + 16 cb + 4 kg + e) ----
   // 32-bit buffer addressing with split offsets (row part + column part; an invalid part = 2^30 makes the sum out of
   // range): a pixel that does not exist (ragged last tile block, H or W not a multiple of 4) loads zeros / drops the store.
-  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)p.y_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y + (long)blockIdx.y * p.y_slice, 0, (int)p.y_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res_mode == 1 ? p.res : p.y), 0,
                                                                  (int)(p.res_mode == 1 ? p.r_bytes : 0u), 0x00020000);
   const int cbase = n0 + 32 * wc + 4 * kg;      // + 16 cb: one store instruction covers 64 contiguous bytes per pixel
@@ -521,7 +526,7 @@ extern "C" int glass_winograd43_pack_weights(const float* w, int Cout, int Cin, 
 }
 
 static int wino43_launch(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias, const float* residual,
-                         float* y, glass_stream_t stream, bool body_only);
+                         float* y, glass_stream_t stream, bool body_only, int splits = 1, void* workspace = nullptr);
 
 extern "C" int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed,
                                              const float* bias, const float* residual, float* y, glass_stream_t stream) {
@@ -539,8 +544,38 @@ extern "C" int glass_conv3x3_winograd43_body_nhwc(const glass_conv_desc* d, cons
   return wino43_launch(d, x, u_packed, bias, residual, y, stream, true);
 }
 
+// Split-K (round 6): the layers whose F(4x4) grid leaves most of the chip idle when ONE image is in flight (reference predictor:
+// glass/inference/glass_runner.py:93-96) - res4 / res5 3x3 on 64 x 64 / 32 x 32 maps (32 / 16 workgroups of 8 / 16 k-tiles), the
+// fusion conv, FPN / RPN on the small levels.  `splits` k-slices of the layer run as gridDim.y (slice s = k-tiles [s nk / splits,
+// (s+1) nk / splits)); a slice's output transform is linear, so it writes its raw partial Y to workspace[s][N H W][Cout] and the
+// ordered reduction of splitk_common.h adds the slices, then bias / ReLU / residual, and writes y with its strides.  With
+// `body_only` the last pixel column of y is written by the reduction from unwritten workspace and must be overwritten by the
+// caller's strip convolution, as after glass_conv3x3_winograd43_body_nhwc.  Wide shape only (Cout % 128 == 0, Cin % 32 == 0).
+extern "C" int glass_winograd43_splitk_supported(const glass_conv_desc* d, int splits) {
+  return glass_winograd43_supported(d) && wino43_wide(d->Cout, d->Cin) && splits >= 2 && splits <= 32 && (d->Cin / 32) % splits == 0 &&
+         (long)d->N * d->H * d->W * d->Cout * 4 < 0x40000000L;
+}
+
+extern "C" int64_t glass_winograd43_splitk_workspace_bytes(const glass_conv_desc* d, int splits) {
+  if (!d) return 0;
+  return (int64_t)splits * d->N * d->H * d->W * d->Cout * (int64_t)sizeof(float);
+}
+
+extern "C" int glass_conv3x3_winograd43_splitk_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
+                                                    const float* residual, float* y, int splits, int body_only, void* workspace,
+                                                    int64_t workspace_bytes, glass_stream_t stream) {
+  GLASS_CHECK_ARG(d && workspace, "glass_conv3x3_winograd43_splitk_nhwc: null pointer");
+  GLASS_CHECK_ARG(glass_winograd43_splitk_supported(d, splits),
+                  "glass_conv3x3_winograd43_splitk_nhwc: needs the wide F(4x4) shape (Cout %% 128 == 0, Cin %% 32 == 0), 2 <= splits <= 32 "
+                  "dividing Cin / 32 (got Cin=%d Cout=%d splits=%d)", d->Cin, d->Cout, splits);
+  GLASS_CHECK_ARG(workspace_bytes >= glass_winograd43_splitk_workspace_bytes(d, splits) && ((uintptr_t)workspace & 15) == 0,
+                  "glass_conv3x3_winograd43_splitk_nhwc: workspace too small or not 16-byte aligned");
+  GLASS_CHECK_ARG(!body_only || d->W >= 4, "glass_conv3x3_winograd43_splitk_nhwc: body_only needs W >= 4");
+  return wino43_launch(d, x, u_packed, bias, residual, y, stream, body_only != 0, splits, workspace);
+}
+
 static int wino43_launch(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias, const float* residual,
-                         float* y, glass_stream_t stream, bool body_only) {
+                         float* y, glass_stream_t stream, bool body_only, int splits, void* workspace) {
   GLASS_CHECK_ARG(d && x && u_packed && y, "glass_conv3x3_winograd43_nhwc: null pointer");
   GLASS_CHECK_ARG(glass_winograd43_supported(d),
                   "glass_conv3x3_winograd43_nhwc: needs 3x3/stride 1/pad 1, Cin%%16==0, Cout%%64==0, unit channel stride, "
@@ -560,7 +595,9 @@ static int wino43_launch(const glass_conv_desc* d, const float* x, const float* 
   p.ntiles = (int)nt;
   const bool wide = wino43_wide(d->Cout, d->Cin);
   const int T4 = wide ? 16 : 32, N4 = wide ? 128 : 64, K4 = wide ? 32 : 16;
-  p.nk = d->Cin / K4;
+  p.nkt = d->Cin / K4;
+  p.nk = p.nkt / splits;
+  p.y_slice = 0;
   p.ldx = d->ldx; p.ldy = d->ldy; p.ycoff = d->y_coff; p.ldr = d->ldr; p.relu = d->relu; p.res_mode = d->res_mode;
   p.tiles_m = cdiv(p.ntiles, T4);
   p.tiles_n = d->Cout / N4;
@@ -570,6 +607,13 @@ static int wino43_launch(const glass_conv_desc* d, const float* x, const float* 
   p.u_bytes = (unsigned)(36L * d->Cout * d->Cin * 4);
   p.y_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldy * 4);
   p.r_bytes = d->res_mode == 1 ? (unsigned)((long)d->N * d->H * d->W * d->ldr * 4) : 0u;
+  const long Mpix = (long)d->N * d->H * d->W;
+  if (splits > 1) {       // the slices write raw partial sums: dense [M][Cout] rows, no bias / ReLU / residual
+    p.y = static_cast<float*>(workspace); p.bias = nullptr; p.res = nullptr;
+    p.ldy = d->Cout; p.ycoff = 0; p.relu = 0; p.res_mode = 0; p.ldr = 0; p.r_bytes = 0;
+    p.y_slice = Mpix * d->Cout;
+    p.y_bytes = (unsigned)(Mpix * d->Cout * 4);
+  }
   const long nblk = (long)p.tiles_m * p.tiles_n;
   GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv3x3_winograd43_nhwc: bad grid");
   static const int abl = getenv("GLASS_W43_ABL") ? atoi(getenv("GLASS_W43_ABL")) : 0;      // timing ablations (wrong results)
@@ -592,8 +636,13 @@ static int wino43_launch(const glass_conv_desc* d, const float* x, const float* 
     glass_set_error("glass_conv3x3_winograd43_nhwc: cannot reserve %d bytes of LDS (hip error %d)", WINO43_LDS_BYTES, attr_rc);
     return GLASS_EHIP;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), WINO43_LDS_BYTES, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)splits), dim3(256), WINO43_LDS_BYTES, (hipStream_t)stream, p);
   GLASS_CHECK_LAUNCH("glass_conv3x3_winograd43_nhwc");
+  if (splits > 1) {
+    launch_splitk_reduce(static_cast<const float*>(workspace), bias, residual, y, Mpix, d->Cout, splits, d->ldy, d->y_coff, 1, d->ldr, d->relu,
+                         d->res_mode, (hipStream_t)stream);
+    GLASS_CHECK_LAUNCH("glass_conv3x3_winograd43_splitk_nhwc(reduce)");
+  }
   if (abl == 4 && p.dbg) {      // instrumented build: print the phase times of a few workgroups (drains the stream)
     static int printed = 0;
     if (printed++ < (getenv("GLASS_W43_DBG_DUMP") ? 256 : 4)) {

@@ -318,6 +318,7 @@ def _use_f43(N: int, H: int, W: int, Cout: int, Cin: int, body: bool = False) ->
 
 
 NUM_CUS = 256
+_F43_SPLITK = os.environ.get("GLASS_F43_SPLITK", "1") != "0"        # (A/B switch of the F(4x4) split-K routing, read once)
 _SPLIT_LONGK = os.environ.get("GLASS_SPLIT_LONGK", "1") != "0"      # (A/B switch of _use_split's long-k rule, read once)
 
 
@@ -357,8 +358,38 @@ def _small_grid_3x3(N: int, H: int, W: int, Cout: int, Cin: int, can_body: bool,
         t2 = N * ((H + 1) // 2) * (W // 2 if body else (W + 1) // 2)
         blocks = -(-t2 // 32) * (Cout // 128) if wide22 else -(-t2 // 64) * (Cout // 64)
         cands.append((rounds(blocks) * ((9 + 0.30 * Cin) if wide22 else 3.0 * Cin) + strip, "f22", body))
-    _, kind, body = min(cands)
-    return kind, body
+    t, kind, body = min(cands)
+    return kind, body, t
+
+
+def _TLS_force_f43k():
+    return getattr(_TLS, "force_f43k", None)
+
+
+def _f43_splitk_plan(N: int, H: int, W: int, Cout: int, Cin: int, can_body: bool):
+    """Split-K plan of the F(4x4,3x3) kernel (glass_conv3x3_winograd43_splitk_nhwc, wide shape) for a 3x3 / stride-1 layer whose
+    16-tile x 128-channel grid leaves most of the chip idle - one image in flight (reference glass_runner.py:93-96): res4 / res5 3x3
+    on 64 x 64 / 32 x 32 maps are 32 / 16 workgroups of 8 / 16 k-tiles.  Model fitted to scripts/exp_f43_splitk.py on MI355X
+    (profiles/r06_f43_splitk.txt): a launch takes ceil(workgroups / 256) rounds of 17 + 7.5 us per k-tile a workgroup walks,
+    + 8 + 0.3 us per slice for the reduction launch, + the slices' partial outputs once out and once back at ~12 TB/s (they stay in L2 / Infinity
+    Cache at these sizes), + ~25 us for the last-column strip in `body` form.
+    -> (splits, body, modelled us) or None."""
+    if Cout % 128 or Cin % 32:
+        return None
+    nk = Cin // 32
+    best = None
+    for body in ((False, True) if (can_body and W % 4 == 1) else (False,)):
+        t4 = N * ((H + 3) // 4) * (W // 4 if body else (W + 3) // 4)
+        blocks = -(-t4 // 16) * (Cout // 128)
+        if blocks > NUM_CUS // 4:       # a quarter of the chip or less: with more, and two steps in flight, the other step's kernels
+            continue                    # already fill the idle CUs and the split only adds a launch (8-image bench: 310.0 vs 309.0)
+        for sl in (2, 3, 4, 6, 8, 12, 16, 24, 32):
+            if nk % sl or blocks * sl > NUM_CUS:
+                continue
+            t = -(-(blocks * sl) // NUM_CUS) * (17.0 + 7.5 * nk / sl) + 8.0 + 0.3 * sl + 2.0 * sl * N * H * W * Cout * 4 / 12e6 + (25.0 if body else 0.0)
+            if best is None or t < best[2]:
+                best = (sl, body, t)
+    return best
 
 
 class ConvWeight:
@@ -602,6 +633,7 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     ragged = strip_ok and W % 4 == 1
     f43 = winograd == "f43" or (winograd is None and rt.f43 and use_wino and KH == 3 and _use_f43(N, H, W, Cout, Cin, ragged))
     f22_body = False
+    t_alt = None                                    # modelled time of the launch the layer takes otherwise (small grids only)
     if winograd == "f22r":                          # forced: F(2x2) on the full tile columns + the last-column strip (tests)
         if not strip_ok:
             raise GlassLibraryError("winograd='f22r' needs an odd width >= 5, dense input, unit channel stride and res_mode 0/1")
@@ -609,9 +641,35 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     if (winograd is None and use_wino and not f43 and KH == 3 and KW == 3 and rt.small_grid and
             lib().glass_winograd_supported(ctypes.byref(d))):
         # the F(4x4) grid does not fill the chip (one image in flight): rounds x workgroup time decides
-        kind, body = _small_grid_3x3(N, H, W, Cout, Cin, strip_ok,
-                                     rt.f43 and bool(lib().glass_winograd43_supported(ctypes.byref(d))))
+        kind, body, t_alt = _small_grid_3x3(N, H, W, Cout, Cin, strip_ok,
+                                            rt.f43 and bool(lib().glass_winograd43_supported(ctypes.byref(d))))
         f43, ragged, f22_body = kind == "f43", kind == "f43" and body, kind == "f22" and body
+    # round 6: the same layers - and the ones the rule above already sent to the implicit-GEMM kernel - as a SPLIT-K launch of the
+    # F(4x4) kernel when the model says it is >= 15 % faster than what they take otherwise
+    if (_F43_SPLITK and winograd is None and rt.winograd and rt.f43 and rt.small_grid and rt.splitk and rt.precision == "fp32" and KH == 3 and KW == 3 and
+            _pair(stride) == (1, 1) and x.dtype == torch.float32 and out.dtype == torch.float32 and out_cstride == 1 and res_mode in (0, 1) and
+            not _use_f43(N, H, W, Cout, Cin, strip_ok and W % 4 == 1) and (not isinstance(w, ConvWeight) or True in w.packs)):
+        plan = _f43_splitk_plan(N, H, W, Cout, Cin, strip_ok and (not isinstance(w, ConvWeight) or "col1" in w.packs))
+        if _TLS_force_f43k() is not None:           # (scripts/exp_f43_splitk.py: force a slice count to fit the model; 0 = never)
+            fs = _TLS_force_f43k()                  # slices, or (slices, body)
+            fs = fs if isinstance(fs, tuple) else (fs, False)
+            plan, t_alt = ((int(fs[0]), bool(fs[1]) and strip_ok and W % 4 == 1, 0.0) if fs[0] else None), None
+        if plan is not None:
+            sl, body, t_sk = plan
+            if t_alt is None:
+                t_alt = _splitk_slices(rt, N * Ho * Wo, KH * KW * Cin, Cin, Cout, want_time=True)[1] if not use_wino else None
+            if (t_alt is None or t_sk < (0.8 if body else 0.85) * t_alt) and lib().glass_winograd43_splitk_supported(ctypes.byref(d), sl):
+                nbytes = int(lib().glass_winograd43_splitk_workspace_bytes(ctypes.byref(d), sl))
+                ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+                check(lib().glass_conv3x3_winograd43_splitk_nhwc(
+                    ctypes.byref(d), c_void_p(_dev(x, "x")), c_void_p(_dev(_packed(w, wt, True), "w")),
+                    c_void_p(_dev(bias, "bias") if bias is not None else None),
+                    c_void_p(_dev(residual, "residual") if residual is not None else None), c_void_p(_dev(out, "out")), int(sl), int(body),
+                    c_void_p(_dev(ws)), ctypes.c_int64(nbytes), c_void_p(stream_handle())), "glass_conv3x3_winograd43_splitk_nhwc")
+                if body:
+                    _last_column_strip(x, _packed(w, wt, "col1"), bias, residual, out, d, out_coff)
+                _TLS.last_path = "winograd43k"        # (bench / profiling: F(4x4) split-K + reduction)
+                return out
     if use_wino and f43 and KH == 3 and KW == 3 and lib().glass_winograd43_supported(ctypes.byref(d)):
         if ragged:
             # width 4 k + 1: the F(4x4) kernel on the k full tile columns - 32 instead of 36 tiles per 16 x 33 map, and e.g.
@@ -667,7 +725,7 @@ def _last_column_strip(x: torch.Tensor, wcol: torch.Tensor, bias, residual, out:
                                   c_void_p(stream_handle())), "glass_conv2d_nhwc(last column)")
 
 
-def _splitk_slices(rt: Routing, M: int, Ktot: int, Cin: int, Cout: int) -> int:
+def _splitk_slices(rt: Routing, M: int, Ktot: int, Cin: int, Cout: int, want_time: bool = False):
     """k-slices for an implicit-GEMM launch that is latency-bound behind a long k-loop (0: a single slice).  Cost model from
     scripts/exp_small_grid.py on MI355X (64 x 64 tiles, 8 workgroups resident per CU; 128 x 32 for Cout <= 32): a workgroup
     alone on its CU takes ~0.75 us per 32-deep k-tile (load -> LDS -> barrier latency), w > 1 workgroups per CU take
@@ -676,10 +734,10 @@ def _splitk_slices(rt: Routing, M: int, Ktot: int, Cin: int, Cout: int) -> int:
     reduction launch.  The split is taken when it saves >= 15 %.
     (box head fc1, 12544 -> 2048: 100 rows 298 -> 64 us with 8 slices, 800 rows 424 -> 348; res5 3x3 at 32 x 32: 112 -> 47.)"""
     if not rt.splitk or rt.precision != "fp32" or Cin % 32 != 0 or M <= 0:
-        return 0
+        return (0, float("inf")) if want_time else 0
     nk = Ktot // 32
     if nk < 16:
-        return 0
+        return (0, float("inf")) if want_time else 0
     tiles = -(-M // 128) if Cout <= 32 else -(-M // 64) * -(-Cout // 64)
 
     def t(s):
@@ -690,6 +748,8 @@ def _splitk_slices(rt: Routing, M: int, Ktot: int, Cin: int, Cout: int) -> int:
     for s in (2, 3, 4, 6, 7, 8, 9, 12, 14, 16, 18, 24, 28, 32):
         if nk % s == 0 and nk // s >= 4 and t(s) < tbest:
             best, tbest = s, t(s)
+    if want_time:
+        return best, (tbest if best else t(1))
     return best
 
 

@@ -141,6 +141,19 @@ int glass_conv3x3_winograd43_nhwc(const glass_conv_desc* d, const float* x, cons
  * channels = (kw, cin), see glass_amd/ops/native.py).  Same descriptor (the TRUE H, W), epilogue and errors.          */
 int glass_conv3x3_winograd43_body_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
                                        const float* residual, float* y, glass_stream_t stream);
+/* Split-K form of the F(4x4,3x3) entry (ABI 7; wide shape only: Cout % 128 == 0, Cin % 32 == 0): `splits` (2..32, dividing Cin / 32)
+ * k-slices of the layer run as independent workgroups, each writes the raw partial output of its slice to
+ * workspace[slice][N H W][Cout] (>= glass_winograd43_splitk_workspace_bytes, 16-byte aligned), and an ordered reduction adds the
+ * slices (deterministic), applies bias / ReLU / residual and writes y with the descriptor's strides.  For the 3x3 layers whose
+ * 16-tile x 128-channel grid leaves most of the chip idle when ONE image is in flight - the reference predictor's batch,
+ * glass/inference/glass_runner.py:93-96: res4 / res5 3x3 layers, the fusion conv, FPN / RPN on the small levels.  `body_only` != 0:
+ * full tile columns only, as glass_conv3x3_winograd43_body_nhwc (the caller's strip convolution must follow: the reduction
+ * writes the last pixel column from unwritten workspace).                                                                 */
+int glass_winograd43_splitk_supported(const glass_conv_desc* d, int splits);
+int64_t glass_winograd43_splitk_workspace_bytes(const glass_conv_desc* d, int splits);
+int glass_conv3x3_winograd43_splitk_nhwc(const glass_conv_desc* d, const float* x, const float* u_packed, const float* bias,
+                                         const float* residual, float* y, int splits, int body_only, void* workspace,
+                                         int64_t workspace_bytes, glass_stream_t stream);
 /* ... and the F(2x2,3x3) kernel restricted to its full tile columns: output columns [0, 2 * (W / 2)) (W >= 2), packed
  * weights of glass_winograd_pack_weights.  With one image in flight the 16 x 33 maps of 32 RoIs are 272 workgroups on the full
  * grid (two rounds on 256 CUs) and exactly 256 on the body grid; the last column is the same strip convolution.           */

@@ -297,6 +297,50 @@ def test_conv_splitk_matches_the_single_slice_kernel(shape):
     assert float(a[..., :4].abs().max()) == 0.0 and float(a[..., 4 + Cout:].abs().max()) == 0.0      # the window's neighbours untouched
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64, 256, 256, False, 8), (1, 32, 32, 512, 512, False, 16), (32, 8, 32, 512, 256, False, 4), (1, 128, 128, 256, 256, True, 2),
+                                   (3, 16, 33, 256, 256, True, 2), (3, 16, 33, 256, 256, True, (4, True)), (2, 13, 18, 128, 128, True, 4), (1, 64, 64, 256, 256, True, 2)])
+def test_winograd43_splitk_matches_the_single_launch_and_torch(shape):
+    """glass_conv3x3_winograd43_splitk_nhwc (round 6): k-slices of the F(4x4,3x3) kernel as gridDim.y, raw partial outputs through a
+    workspace, ordered reduction with bias / ReLU / residual and a channel-offset output - against the single-launch F(4x4) kernel and
+    torch CPU fp64, for every forced slice count incl. ragged maps (H, W not multiples of 4), the 16 x 33 maps in body + strip form,
+    and twice (deterministic).  Reference call sites: the 3x3 layers of d2's ResNet / FPN / RPN behind glass_rcnn.py:83,87 and
+    fusion_modules.py:156 with ONE image in flight (glass_runner.py:93-96)."""
+    from glass_amd.ops import native as K
+    dev = _dev()
+    N, H, W, Cin, Cout, res, sl = shape
+    x = _rand((N, H, W, Cin), 71).to(dev)
+    w = K.prepare_conv_weights(_rand((Cout, 3, 3, Cin), 72, (2.0 / (9 * Cin)) ** 0.5).to(dev), "all", ragged=(W % 4 == 1))
+    b = _rand((Cout,), 73, 0.1).to(dev)
+    r = _rand((N, H, W, Cout), 74).to(dev) if res else None
+    kw = dict(padding=1, relu=1, residual=r, res_mode=1 if res else 0)
+    out_a = torch.zeros((N, H, W, Cout + 8), device=dev)
+    out_b = torch.zeros((N, H, W, Cout + 8), device=dev)
+    K._TLS.force_f43k = sl
+    try:
+        a = K.conv2d_nhwc(x, w, b, out=out_a, out_coff=4, **kw)
+        assert K.last_conv_path() == "winograd43k"
+        a2 = K.conv2d_nhwc(x, w, b, **kw)
+        a3 = K.conv2d_nhwc(x, w, b, **kw)
+    finally:
+        K._TLS.force_f43k = None
+    K._TLS.force_f43k = 0
+    try:
+        u = K.conv2d_nhwc(x, w, b, winograd="f43", out=out_b, out_coff=4, **kw)
+    finally:
+        K._TLS.force_f43k = None
+    assert torch.equal(a2, a3) and torch.equal(a2, a[..., 4:4 + Cout])
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.raw.permute(0, 3, 1, 2).double().cpu(), b.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.double().cpu()
+    ref = F.relu(ref)
+    scale = float(ref.abs().max())
+    e = float((a[..., 4:4 + Cout].double().cpu() - ref).abs().max()) / scale
+    print(f"F(4x4) split-K x{sl} [{N},{H},{W},{Cin}]->{Cout}: max err / range = {e:.2e}")
+    assert e <= 1e-5, e
+    assert float((a - u).abs().max()) <= 1e-5 * scale
+    assert float(a[..., :4].abs().max()) == 0.0 and float(a[..., 4 + Cout:].abs().max()) == 0.0      # the window's neighbours untouched
+
+
 def test_backbone_stem_fused_matches_the_two_launches_and_torch():
     """glass_backbone_stem_fused (conv 7x7 s2 p3 + bias + ReLU + max_pool2d(3, 2, 1) in one kernel, csrc/backbone_stem.hip) against
     the two launches it replaces and, on the smaller shapes, against torch CPU fp64 - shapes that cross the kernel's seams: more
