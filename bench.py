@@ -156,11 +156,24 @@ class ConvMeter:
                                            (64, 7, 7))
         self.K.local_stem_fused = timed(self.orig_lstem, lambda x: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 9 * (16 * 3 + 32 * 16),
                                         (32, 3, 3))
+        # a bottleneck block's shortcut + conv3 as one dual-source launch of the bf16-split kernel: the direct-convolution FLOP of BOTH convs
+        self.orig_dual = self.K.conv1x1_dual_nhwc
+
+        def dual(x1, x2, w, bias=None, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self.orig_dual(x1, x2, w, bias, **kw)
+            e1.record()
+            algo = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * y.shape[3] * w.shape[3]
+            self.steps[-1].append(("pointwise_split", tuple(x1.shape), (y.shape[3], 1, 1), kw.get("stride", 1), True, algo, 9.0 * algo, e0, e1))
+            return y
+        self.K.conv1x1_dual_nhwc = dual
         return self
 
     def __exit__(self, *a):
         self.K.conv2d_nhwc = self.orig
         self.K.backbone_stem_fused, self.K.local_stem_fused = self.orig_bstem, self.orig_lstem
+        self.K.conv1x1_dual_nhwc = self.orig_dual
 
     def _launches(self):
         """[(family, x shape, w dims, stride, +res, algo, exec, median ms)] in launch order"""

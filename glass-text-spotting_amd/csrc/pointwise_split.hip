@@ -38,6 +38,9 @@ struct PwsParams {
   unsigned x_bytes, u_bytes, y_bytes, r_bytes;
   unsigned magic_hw, magic_w;                 // floor(2^32 / (Ho*Wo)), floor(2^32 / Wo)
   unsigned long long* dbg;                    // timing build (-DGLASS_PWS_STAMPS) only
+  // DUAL form (a bottleneck block's shortcut folded into its conv3: Y = [X1(strided) | X2] [W1 | W2]^T, one accumulator): the
+  // k-tiles [0, nk1) read x (Cin channels, `stride`), the k-tiles [nk1, nk) read x2 [M][ldx2] on the output grid
+  const float* x2; int nk1, ldx2; unsigned x2_bytes;
 };
 
 #ifdef GLASS_PWS_STAMPS   // scripts/build_variant_lib.sh pwst -DGLASS_PWS_STAMPS: phase totals of wavefront 0 of a mid-grid workgroup
@@ -63,7 +66,7 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, unsigned& hp, un
   lp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{l0, l1}), bf16x2));
 }
 
-template <int PB, int NPROD>
+template <int PB, int NPROD, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_pw_split(PwsParams p) {
   constexpr int PX = 16 * PB;                 // pixels per block
   constexpr int XL = PX / 32;                 // input float4 loads per thread and k-tile
@@ -106,16 +109,32 @@ __global__ __launch_bounds__(256, 2) void conv1x1_pw_split(PwsParams p) {
     }
     xoff[i] = off;
   }
+  unsigned xoff2[DUAL ? XL : 1];
+  __amdgpu_buffer_rsrc_t xr2 = xr;
+  if constexpr (DUAL) {
+    xr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2), 0, (int)p.x2_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int m = m0 + prow + 8 * NW * i;
+      xoff2[i] = m < p.M ? (unsigned)(m * p.ldx2 + chunk * 4) * 4u : OOB;
+    }
+  }
   // (requesting the pixels two k-tiles ahead into a second register set, three workgroups per CU by launch bound, or eight
   //  wavefronts x 32 channels per block so that a pixel tile is split once for 256 channels: measured equal or slower - the
   //  kernel runs at the package power cap, profiles/r05_pw_split.txt)
   float4 xreg[XL];
-  auto load_x1 = [&](int i, int kt) {
-    xreg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[i], kt * (SK * 4), 0));
-  };
   auto load_x = [&](int kt) {
+    if constexpr (DUAL) {
+      if (kt >= p.nk1) {                      // uniform: the second source's k-tiles
 #pragma unroll
-    for (int i = 0; i < XL; ++i) load_x1(i, kt);
+        for (int i = 0; i < XL; ++i)
+          xreg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr2, xoff2[i], (kt - p.nk1) * (SK * 4), 0));
+        return;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i)
+      xreg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[i], kt * (SK * 4), 0));
   };
   // plane q: [pixel][4 slots of 16 bytes = 8 k each], slot ^= (pixel / 4) % 4; this thread's 4 k are half (chunk & 1) of slot chunk >> 1
   auto store_x1 = [&](int i, int stage) {
@@ -321,6 +340,11 @@ extern "C" int glass_pointwise_split_pack_weights(const float* w, int Cout, int 
   return GLASS_OK;
 }
 
+namespace {
+int pws_launch(const glass_conv_desc* d, const float* x, const float* x2, int Cin2, int ldx2, const void* u_packed, const float* bias,
+               const float* residual, float* y, int products, glass_stream_t stream, const char* who);
+}
+
 // products: 9 = every pair of pieces (the exact product; what the model path uses); 6 = without the three terms < 2^-23 (measurement only)
 extern "C" int glass_conv1x1_pointwise_split_nhwc(const glass_conv_desc* d, const float* x, const void* u_packed, const float* bias,
                                                   const float* residual, float* y, int products, glass_stream_t stream) {
@@ -334,13 +358,20 @@ extern "C" int glass_conv1x1_pointwise_split_nhwc(const glass_conv_desc* d, cons
                       (bias == nullptr || ((uintptr_t)bias & 15) == 0) && (residual == nullptr || ((uintptr_t)residual & 15) == 0),
                   "glass_conv1x1_pointwise_split_nhwc: pointers must be 16-byte aligned");
   if (d->N == 0) return GLASS_OK;
+  return pws_launch(d, x, nullptr, 0, 0, u_packed, bias, residual, y, products, stream, "glass_conv1x1_pointwise_split_nhwc");
+}
+
+namespace {
+int pws_launch(const glass_conv_desc* d, const float* x, const float* x2, int Cin2, int ldx2, const void* u_packed, const float* bias,
+               const float* residual, float* y, int products, glass_stream_t stream, const char* who) {
   PwsParams p;
   p.x = x; p.u = u_packed; p.bias = bias; p.res = residual; p.y = y;
   p.M = d->N * d->Ho * d->Wo; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.Cin = d->Cin; p.Cout = d->Cout;
-  p.stride = d->stride_h; p.nk = d->Cin / SK;
+  p.stride = d->stride_h; p.nk1 = d->Cin / SK; p.nk = (d->Cin + Cin2) / SK;
+  p.x2 = x2; p.ldx2 = ldx2; p.x2_bytes = (unsigned)((long)p.M * ldx2 * 4);
   p.ldx = d->ldx; p.ldy = d->ldy; p.ycoff = d->y_coff; p.ldr = d->ldr; p.relu = d->relu; p.res_mode = d->res_mode;
   p.x_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldx * 4);
-  p.u_bytes = (unsigned)((long)d->Cout * d->Cin * 6);
+  p.u_bytes = (unsigned)((long)d->Cout * (d->Cin + Cin2) * 6);
   p.y_bytes = (unsigned)((long)p.M * d->ldy * 4);
   p.r_bytes = d->res_mode == 1 ? (unsigned)((long)p.M * d->ldr * 4)
             : d->res_mode == 2 ? (unsigned)((long)d->N * (d->Ho / 2) * (d->Wo / 2) * d->ldr * 4) : 0u;
@@ -357,15 +388,45 @@ extern "C" int glass_conv1x1_pointwise_split_nhwc(const glass_conv_desc* d, cons
   const bool big = (long)cdiv(p.M, 128) * p.tiles_n >= 512;
   p.tiles_m = cdiv(p.M, big ? 128 : 64);
   const long nblk = (long)p.tiles_m * p.tiles_n;
-  GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "glass_conv1x1_pointwise_split_nhwc: bad grid");
+  GLASS_CHECK_ARG(nblk > 0 && nblk <= 0x7fffffffL, "%s: bad grid", who);
   const dim3 grid((unsigned)nblk), block(256);
-  if (products == 9) {
+  if (x2 != nullptr) {
+    if (big) hipLaunchKernelGGL((conv1x1_pw_split<8, 9, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv1x1_pw_split<4, 9, true>), grid, block, 0, s, p);
+  } else if (products == 9) {
     if (big) hipLaunchKernelGGL((conv1x1_pw_split<8, 9>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv1x1_pw_split<4, 9>), grid, block, 0, s, p);
   } else {
     if (big) hipLaunchKernelGGL((conv1x1_pw_split<8, 6>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv1x1_pw_split<4, 6>), grid, block, 0, s, p);
   }
-  GLASS_CHECK_LAUNCH("glass_conv1x1_pointwise_split_nhwc");
+  GLASS_CHECK_LAUNCH(who);
   return GLASS_OK;
+}
+}  // namespace
+
+// The shortcut of a bottleneck block folded into its conv3 (reference: detectron2 BottleneckBlock.forward behind
+// glass/modeling/meta_arch/glass_rcnn.py:83, `out = conv3(out); out += shortcut(x); relu` [d2-recall]):
+//   y = act([x1 strided | x2] . [W1 | W2]^T + bias)      x1 [N,H,W,ldx] with the desc's stride (the block input, Cin = d->Cin),
+//   x2 [N,Ho,Wo,ldx2] (conv2's output, Cin2 channels), u_packed = glass_pointwise_split_pack_weights of the [Cout][Cin + Cin2]
+//   concatenation, bias = the sum of the two folded biases.  One accumulator, nine exact bf16 piece products per element as in
+//   glass_conv1x1_pointwise_split_nhwc: the [M][Cout] shortcut map is never written nor read back (res2: 2 x 537 MB at 8 images).
+extern "C" int glass_pointwise_split_dual_supported(const glass_conv_desc* d, int Cin2, int ldx2) {
+  if (!d || !glass_pointwise_split_supported(d)) return 0;
+  const long M = (long)d->N * d->Ho * d->Wo;
+  return d->res_mode == 0 && Cin2 > 0 && Cin2 % SK == 0 && ldx2 % 4 == 0 && ldx2 >= Cin2 && M * ldx2 * 4 < 0x7fffff00L &&
+         (long)d->Cout * (d->Cin + Cin2) * 6 < 0x7fffff00L;
+}
+
+extern "C" int glass_conv1x1_pointwise_split_dual_nhwc(const glass_conv_desc* d, const float* x1, const float* x2, int Cin2, int ldx2,
+                                                       const void* u_packed, const float* bias, float* y, glass_stream_t stream) {
+  GLASS_CHECK_ARG(d && x1 && x2 && u_packed && y, "glass_conv1x1_pointwise_split_dual_nhwc: null pointer");
+  GLASS_CHECK_ARG(glass_pointwise_split_dual_supported(d, Cin2, ldx2),
+                  "glass_conv1x1_pointwise_split_dual_nhwc: needs what glass_conv1x1_pointwise_split_nhwc needs, res_mode 0, Cin2%%32==0, "
+                  "ldx2%%4==0, ldx2>=Cin2 (got Cin=%d Cin2=%d ldx2=%d Cout=%d res_mode=%d)", d->Cin, Cin2, ldx2, d->Cout, d->res_mode);
+  GLASS_CHECK_ARG(((uintptr_t)x1 & 15) == 0 && ((uintptr_t)x2 & 15) == 0 && ((uintptr_t)u_packed & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                      (bias == nullptr || ((uintptr_t)bias & 15) == 0),
+                  "glass_conv1x1_pointwise_split_dual_nhwc: pointers must be 16-byte aligned");
+  if (d->N == 0) return GLASS_OK;
+  return pws_launch(d, x1, x2, Cin2, ldx2, u_packed, bias, nullptr, y, 9, stream, "glass_conv1x1_pointwise_split_dual_nhwc");
 }

@@ -21,7 +21,7 @@ SO_PATH = os.environ.get("GLASS_HIP_LIB") or os.path.join(_ROOT, "libglass_hip.s
 EXPORTS = [
     "glass_last_error", "glass_abi_version", "glass_device_count", "glass_conv2d_nhwc", "glass_conv2d_nhwc_f16", "glass_conv2d_nhwc_h16", "glass_local_stem_supported", "glass_local_stem_fused", "glass_local_stem_fused_h16", "glass_backbone_stem_supported", "glass_backbone_stem_fused", "glass_conv3x3_winograd43_body_nhwc", "glass_winograd43_splitk_supported", "glass_winograd43_splitk_workspace_bytes", "glass_conv3x3_winograd43_splitk_nhwc", "glass_roi_align_rotated_up2", "glass_conv2d_splitk_supported", "glass_conv2d_splitk_workspace_bytes", "glass_conv2d_nhwc_splitk", "glass_conv3x3_winograd_body_nhwc",
     "glass_pointwise_supported", "glass_pointwise_weight_floats", "glass_pointwise_pack_weights", "glass_conv1x1_pointwise_nhwc",
-    "glass_pointwise_split_supported", "glass_pointwise_split_weight_bytes", "glass_pointwise_split_pack_weights", "glass_conv1x1_pointwise_split_nhwc",
+    "glass_pointwise_split_supported", "glass_pointwise_split_weight_bytes", "glass_pointwise_split_pack_weights", "glass_conv1x1_pointwise_split_nhwc", "glass_pointwise_split_dual_supported", "glass_conv1x1_pointwise_split_dual_nhwc",
     "glass_conv_h16_supported", "glass_conv_h16_weight_halves", "glass_conv_h16_pack_weights", "glass_conv2d_nhwc_h16_packed",
     "glass_winograd_supported", "glass_winograd_block_channels", "glass_winograd_weight_floats", "glass_winograd_pack_weights", "glass_conv3x3_winograd_nhwc",
     "glass_winograd43_supported", "glass_winograd43_weight_floats", "glass_winograd43_pack_weights", "glass_conv3x3_winograd43_nhwc",
@@ -50,7 +50,7 @@ class GlassLibraryError(RuntimeError):
 DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 
 
-ABI_VERSION = 7      # what csrc/common.hip glass_abi_version() returns: bumped whenever include/glass_hip.h gains or changes an entry
+ABI_VERSION = 8      # what csrc/common.hip glass_abi_version() returns: bumped whenever include/glass_hip.h gains or changes an entry
 
 
 def sources() -> List[str]:

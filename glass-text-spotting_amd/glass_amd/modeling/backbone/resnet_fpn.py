@@ -65,6 +65,12 @@ class ResNetFPN(InferenceModule):
                 for cname in ("conv1", "conv2", "conv3", "shortcut"):
                     if (q + cname + ".weight") in sd:
                         w[f"{sname}.{b}.{cname}"] = fold_conv(sd, q + cname, q + cname + ".norm", device)
+                if f"{sname}.{b}.shortcut" in w:
+                    # relu(conv3(out) + shortcut(x)) as ONE dual-source launch: [W_shortcut | W_conv3] along Cin, the two folded biases summed
+                    (wsc, bsc), (w3, b3) = w[f"{sname}.{b}.shortcut"], w[f"{sname}.{b}.conv3"]
+                    dual = K.prepare_dual_weights(wsc, w3)
+                    if dual is not None and bsc is not None and b3 is not None:
+                        w[f"{sname}.{b}.dual"] = (dual, (bsc + b3).contiguous())
         for lvl in (2, 3, 4, 5):
             w[f"lat{lvl}"] = fold_conv(sd, f"{prefix}fpn_lateral{lvl}", f"{prefix}fpn_lateral{lvl}.norm", device)
             w[f"out{lvl}"] = fold_conv(sd, f"{prefix}fpn_output{lvl}", f"{prefix}fpn_output{lvl}.norm", device)
@@ -86,9 +92,14 @@ class ResNetFPN(InferenceModule):
             for b in range(nblk):
                 stride = 2 if (b == 0 and sname != "res2") else 1
                 key = f"{sname}.{b}."
-                sc = K.conv2d_nhwc(x, *w[key + "shortcut"], stride=stride) if (key + "shortcut") in w else x
                 out = K.conv2d_nhwc(x, *w[key + "conv1"], stride=stride, relu=1)
                 out = K.conv2d_nhwc(out, *w[key + "conv2"], padding=1, relu=1)
+                dual = w.get(key + "dual")
+                if dual is not None and K.dual_supported(x, out, dual[0], stride):
+                    # first block of a stage: the shortcut conv rides in conv3's k-loop (x then conv2's output), its map never reaches HBM
+                    x = K.conv1x1_dual_nhwc(x, out, dual[0], dual[1], stride=stride, relu=1)
+                    continue
+                sc = K.conv2d_nhwc(x, *w[key + "shortcut"], stride=stride) if (key + "shortcut") in w else x
                 x = K.conv2d_nhwc(out, *w[key + "conv3"], relu=1, residual=sc, res_mode=1)
             feats[sname] = x
         res: Dict[str, torch.Tensor] = {}

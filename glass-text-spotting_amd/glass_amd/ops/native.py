@@ -709,6 +709,66 @@ def conv2d_nhwc(x: torch.Tensor, w, bias: Optional[torch.Tensor] = None, *, stri
     return launch("glass_conv2d_nhwc", "direct", x, wt)
 
 
+_DUAL = os.environ.get("GLASS_PW_DUAL", "1") != "0"                # (A/B switch of the shortcut-into-conv3 fusion, read once)
+
+
+def prepare_dual_weights(w1, w2) -> Optional["ConvWeight"]:
+    """the [Cout,1,1,Cin1+Cin2] concatenation (w1 first) of two 1x1 layers that write the SAME output - a bottleneck block's
+    shortcut and conv3 - with the bf16-split pack of conv1x1_dual_nhwc; None when the load's routing has no exact split kernel
+    (fp16 modes, split 0 / 6) or the shapes do not fit it.  Load-time plumbing next to prepare_conv_weights."""
+    r1, r2 = _raw(w1), _raw(w2)
+    load = getattr(_TLS, "load", None)
+    rt = load if load is not None else _DEFAULT
+    if (not _DUAL or rt.precision != "fp32" or rt.split != 9 or not r1.is_cuda or r1.shape[1:3] != (1, 1) or r2.shape[1:3] != (1, 1) or
+            r1.shape[0] != r2.shape[0] or r1.shape[0] % 128 or r1.shape[3] % 32 or r2.shape[3] % 32):
+        return None
+    cw = ConvWeight(torch.cat([r1, r2], dim=3).contiguous(), routing=load)
+    cw.packs["pws"] = winograd_pack(cw.raw, "pws")
+    if load is None:
+        torch.cuda.current_stream().synchronize()
+    return cw
+
+
+def dual_supported(x1: torch.Tensor, x2: torch.Tensor, w, stride: int = 1, routing: Optional[Routing] = None) -> bool:
+    """does conv1x1_dual_nhwc take this pair (and does the routing want it: same grid rule as the single-source split kernel)"""
+    if w is None or not isinstance(w, ConvWeight) or "pws" not in w.packs:
+        return False
+    rt = routing if routing is not None else routing_of(w)
+    if rt.precision != "fp32" or rt.split != 9 or x1.dtype != torch.float32 or x2.dtype != torch.float32:
+        return False
+    N, H, W, ldx = x1.shape
+    Cout, Cin2 = w.raw.shape[0], x2.shape[3]
+    Cin1 = w.raw.shape[3] - Cin2
+    Ho, Wo = conv_out_size(H, W, 1, 1, stride, 0)
+    if Cin1 <= 0 or ldx != Cin1 or tuple(x2.shape[:3]) != (N, Ho, Wo) or not _use_split(N * Ho * Wo, Cin1 + Cin2, Cout):
+        return False
+    d = ConvDesc(N, H, W, Cin1, Cout, 1, 1, stride, stride, 0, 0, Ho, Wo, ldx, Cout, 0, 1, 0, 0, 0)
+    return bool(lib().glass_pointwise_split_dual_supported(ctypes.byref(d), Cin2, x2.shape[3]))
+
+
+def conv1x1_dual_nhwc(x1: torch.Tensor, x2: torch.Tensor, w: "ConvWeight", bias: Optional[torch.Tensor] = None, *, stride: int = 1,
+                      relu: int = 0) -> torch.Tensor:
+    """y = act([x1 strided | x2] . w^T + bias): a bottleneck block's `relu(conv3(out) + shortcut(x))` (detectron2 BottleneckBlock behind
+    reference glass/modeling/meta_arch/glass_rcnn.py:83 [d2-recall]) as ONE launch of the exact bf16-split kernel with one accumulator -
+    x1 [N,H,W,Cin1] the block input (the shortcut's operand, `stride`), x2 [N,Ho,Wo,Cin2] conv2's output, `w` from prepare_dual_weights,
+    `bias` the sum of the two folded biases.  The [N,Ho,Wo,Cout] shortcut map is neither written nor read back."""
+    _f32c(x1, "x1"); _f32c(x2, "x2")
+    N, H, W, ldx = x1.shape
+    Cout, Cin2 = w.raw.shape[0], x2.shape[3]
+    Cin1 = w.raw.shape[3] - Cin2
+    Ho, Wo = conv_out_size(H, W, 1, 1, stride, 0)
+    if tuple(x2.shape[:3]) != (N, Ho, Wo) or ldx != Cin1:
+        raise GlassLibraryError(f"conv1x1_dual_nhwc: x1 {tuple(x1.shape)} (stride {stride}) and x2 {tuple(x2.shape)} do not share an output grid / weight {tuple(w.raw.shape)}")
+    out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x1.device)
+    d = ConvDesc(N, H, W, Cin1, Cout, 1, 1, stride, stride, 0, 0, Ho, Wo, ldx, Cout, 0, 1, relu, 0, 0)
+    _TLS.last_path = "pointwise_split"
+    check(lib().glass_conv1x1_pointwise_split_dual_nhwc(
+        ctypes.byref(d), c_void_p(_dev(x1, "x1")), c_void_p(_dev(x2, "x2")), int(Cin2), int(x2.shape[3]), c_void_p(_dev(_packed(w, w.raw, "pws"), "w")),
+        c_void_p(_dev(bias, "bias") if bias is not None else None), c_void_p(_dev(out, "out")), c_void_p(stream_handle())),
+        "glass_conv1x1_pointwise_split_dual_nhwc")
+    return out
+
+
 def _last_column_strip(x: torch.Tensor, wcol: torch.Tensor, bias, residual, out: torch.Tensor, d: ConvDesc, out_coff: int) -> None:
     """output column W-1 of the 3x3 / pad-1 layer `d`: glass_conv2d_nhwc with KH 3, KW 1, pad (1, 0) on rows re-viewed as ONE
     pixel of W*ld channels - input channels [(W-2)*ldx, W*ldx) = the last two columns (needs ldx == Cin: dense rows), output

@@ -185,6 +185,15 @@ size_t glass_pointwise_split_weight_bytes(int Cout, int Cin);
 int glass_pointwise_split_pack_weights(const float* w, int Cout, int Cin, void* u_packed, glass_stream_t stream);
 int glass_conv1x1_pointwise_split_nhwc(const glass_conv_desc* d, const float* x, const void* u_packed, const float* bias,
                                        const float* residual, float* y, int products, glass_stream_t stream);
+/* A bottleneck block's shortcut folded into its conv3 (detectron2 BottleneckBlock.forward behind reference
+ * glass/modeling/meta_arch/glass_rcnn.py:83: `out = conv3(out); out += shortcut(x); relu` [d2-recall]) - ONE launch, one
+ * accumulator:  y = act([x1 strided | x2] . [W1 | W2]^T + bias).  `d` describes source 1 and the output (x1 [N,H,W,ldx], Cin,
+ * square stride, relu; res_mode must be 0); x2 [N,Ho,Wo,ldx2] carries Cin2 channels on the output grid; `u_packed` is
+ * glass_pointwise_split_pack_weights(Cout, Cin + Cin2) of the two weights concatenated along Cin (W1 first), `bias` the sum of the
+ * two folded biases.  Nine exact piece products per element as above; the [N,Ho,Wo,Cout] shortcut map never reaches HBM.   */
+int glass_pointwise_split_dual_supported(const glass_conv_desc* d, int Cin2, int ldx2);
+int glass_conv1x1_pointwise_split_dual_nhwc(const glass_conv_desc* d, const float* x1, const float* x2, int Cin2, int ldx2,
+                                            const void* u_packed, const float* bias, float* y, glass_stream_t stream);
 
 /* Fused head of the local-crop feature extractor (reference glass/modeling/fusion/local_feature_extraction.py:103-112):
  * conv0_1 (3x3, 3->16) + BN + ReLU, conv0_2 (3x3, 16->32) + BN + ReLU, maxpool1 2x2 in ONE kernel - the two intermediate

@@ -209,6 +209,38 @@ def test_backbone_matches_oracle(model, scene):
         assert _maxdiff(got, ref.numpy()) < TOL * scale, k
 
 
+def test_backbone_dual_source_blocks_match_the_separate_launches(model):
+    """Round 6: the first block of every ResNet stage runs `relu(conv3(out) + shortcut(x))` as ONE dual-source launch of the bf16-split
+    kernel (ResNetFPN.forward_nhwc; detectron2 BottleneckBlock behind reference glass_rcnn.py:83).  Same weights with the dual packs
+    removed = the shortcut launch + conv3 with residual: every pyramid level within 5e-6 of its range (fp32 summation order through ~50 layers).  (test_backbone_matches_oracle
+    above holds the dual path to the oracle.)"""
+    from glass_amd.ops import native as K
+    bb = model.backbone
+    duals = sorted(k for k in bb.w if k.endswith(".dual"))
+    assert duals == ["res2.0.dual", "res3.0.dual", "res4.0.dual", "res5.0.dual"]
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((2, 512, 512, 4), generator=g).to(_dev())
+    x[..., 3] = 0
+    taken = []
+    orig = K.conv1x1_dual_nhwc
+    K.conv1x1_dual_nhwc = lambda *a, **kw: (taken.append(tuple(a[0].shape)), orig(*a, **kw))[1]
+    try:
+        ya = bb.forward_nhwc(x)
+    finally:
+        K.conv1x1_dual_nhwc = orig
+    assert len(taken) >= 3, taken            # 2 x 512 x 512: res2 .. res4 pass the grid rule
+    saved = {k: bb.w.pop(k) for k in duals}
+    try:
+        yb = bb.forward_nhwc(x)
+    finally:
+        bb.w.update(saved)
+    torch.cuda.synchronize()
+    for k in ya:
+        e = float((ya[k] - yb[k]).abs().max()) / float(yb[k].abs().max())
+        print(f"dual-source blocks, level {k}: {e:.2e} of range")
+        assert e <= 5e-6, (k, e)
+
+
 def test_rpn_matches_oracle_teacher_forced(model, scene):
     dev = _dev()
     feats = [scene["feats"][f].permute(0, 2, 3, 1).contiguous().to(dev) for f in model.proposal_generator.in_features]

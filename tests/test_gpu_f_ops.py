@@ -1127,6 +1127,68 @@ def test_pointwise_split_matches_direct_and_torch(case, products):
     assert e <= 5e-6 and ed <= 5e-6 and e <= 1.5 * max(e_direct, e_pw) + 2e-7
 
 
+DUAL_CASES = [
+    # N, H, W, Cin1, Cin2, Cout, stride   (x1 [N,H,W,Cin1] strided, x2 on the output grid)
+    (2, 64, 64, 64, 64, 256, 1),          # res2.0: shortcut 64 -> 256 + conv3 64 -> 256
+    (2, 64, 64, 256, 128, 512, 2),        # res3.0: shortcut 256 -> 512 stride 2 + conv3 128 -> 512
+    (1, 32, 32, 512, 256, 1024, 2),       # res4.0 (64-pixel blocks)
+    (3, 16, 16, 1024, 512, 2048, 2),      # res5.0
+    (1, 19, 37, 96, 32, 128, 1),          # ragged pixel count (703 rows: a partial last block), one k-tile of the second source
+    (1, 21, 35, 32, 160, 128, 2),         # odd map under stride 2 (Ho = 11, Wo = 18), one k-tile of the first source
+]
+
+
+@pytest.mark.parametrize("case", DUAL_CASES)
+def test_pointwise_split_dual_source_matches_the_two_launches_and_torch(case):
+    """glass_conv1x1_pointwise_split_dual_nhwc: relu([x1 strided | x2] [W1 | W2]^T + b1 + b2) - a bottleneck block's shortcut folded into
+    its conv3 - vs torch fp64 of the two convolutions and vs the two single-source launches it replaces (shortcut, then conv3 + residual
+    + ReLU).  Same exact products; only the order of the fp32 additions differs (one accumulator down both k-ranges)."""
+    from glass_amd.ops import native as K
+    N, H, W, C1, C2, Cout, stride = case
+    dev = _dev()
+    x1 = _rand((N, C1, H, W), 91)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x2 = _rand((N, C2, Ho, Wo), 92)
+    w1 = _rand((Cout, C1, 1, 1), 93, (1.0 / C1) ** 0.5)
+    w2 = _rand((Cout, C2, 1, 1), 94, (1.0 / C2) ** 0.5)
+    b1, b2 = _rand((Cout,), 95, 0.1), _rand((Cout,), 96, 0.1)
+    ref = F.relu(F.conv2d(x1.double(), w1.double(), b1.double(), stride=stride) + F.conv2d(x2.double(), w2.double(), b2.double()))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    x1d, x2d, w1d, w2d = nhwc(x1).to(dev), nhwc(x2).to(dev), nhwc(w1).to(dev), nhwc(w2).to(dev)
+    wd = K.prepare_dual_weights(w1d, w2d)
+    assert wd is not None and tuple(wd.shape) == (Cout, 1, 1, C1 + C2)
+    y = K.conv1x1_dual_nhwc(x1d, x2d, wd, (b1 + b2).to(dev), stride=stride, relu=1)
+    sc = K.conv2d_nhwc(x1d, w1d, b1.to(dev), stride=stride, winograd="pws9")
+    y2 = K.conv2d_nhwc(x2d, w2d, b2.to(dev), relu=1, residual=sc, res_mode=1, winograd="pws9")
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (N, Ho, Wo, Cout) and bool(torch.isfinite(y).all())
+    refn = ref.permute(0, 2, 3, 1)
+    scale = float(refn.abs().max())
+    e, e2 = float((y.cpu().double() - refn).abs().max()) / scale, float((y2.cpu().double() - refn).abs().max()) / scale
+    d = float((y - y2).abs().max()) / scale
+    print(f"dual-source split {case}: vs fp64 {e:.2e} (two launches {e2:.2e}), vs the two launches {d:.2e} (of range)")
+    assert e <= 5e-6 and d <= 5e-6 and e <= 1.5 * e2 + 2e-7
+    # no ReLU, no bias
+    y0 = K.conv1x1_dual_nhwc(x1d, x2d, wd, None, stride=stride)
+    ref0 = (F.conv2d(x1.double(), w1.double(), stride=stride) + F.conv2d(x2.double(), w2.double())).permute(0, 2, 3, 1)
+    assert float((y0.cpu().double() - ref0).abs().max()) / float(ref0.abs().max()) <= 5e-6
+
+
+def test_pointwise_split_dual_refuses_what_it_cannot_run():
+    from glass_amd.ops import native as K
+    from glass_amd._lib import GlassLibraryError
+    dev = _dev()
+    w1, w2 = _rand((128, 1, 1, 64), 1).to(dev), _rand((128, 1, 1, 32), 2).to(dev)
+    wd = K.prepare_dual_weights(w1, w2)
+    x1, x2 = _rand((1, 16, 16, 64), 3).to(dev), _rand((1, 16, 16, 32), 4).to(dev)
+    with pytest.raises(GlassLibraryError):
+        K.conv1x1_dual_nhwc(x1, x2[:, :8].contiguous(), wd)                # grids differ
+    assert K.prepare_dual_weights(w1, _rand((256, 1, 1, 32), 5).to(dev)) is None         # different Cout
+    assert K.prepare_dual_weights(_rand((128, 1, 1, 48), 6).to(dev), w2) is None         # Cin1 not a multiple of 32
+    assert not K.dual_supported(x1, x2, wd, 1)      # 256 pixels x 128 channels: 4 workgroups - the routing keeps the two launches
+    assert not K.dual_supported(x1, x2, None, 1)
+
+
 def test_pointwise_split_reads_channel_slices_and_wide_residuals():
     """the input as the first Cin channels of a wider buffer (ldx > Cin) and the residual as the first Cout channels of a wider
     one (ldr > Cout): pixel strides come from the descriptor, not from the channel counts"""
