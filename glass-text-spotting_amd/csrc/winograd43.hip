@@ -25,7 +25,7 @@
 //     transforms of 12 fma per channel) and writes the 36 transformed pairs to LDS V[xi][tile][32], XOR-swizzled
 //     so that the MFMA-side ds_read_b128 (one per 8 MFMAs, feeding 4 k-steps x 2 channel blocks) is conflict free.
 //   * weights never touch LDS: U = G g G^t is pre-packed (glass_winograd43_pack_weights) in MFMA A-fragment order,
-//     each wave streams its own 1 KiB fragments L2 -> registers through a 4-slot ring, three groups ahead.
+//     each wave streams its own 1 KiB fragments L2 -> registers through a 6-slot ring, five groups ahead.
 //   * 576 MFMAs (18.4 K cycles) per wave and k-tile against 144 weight loads + 72 LDS reads + 36 patch loads + 36 LDS
 //     writes + ~300 VALU (round 6: 1367 instructions per k-tile, 1656 in round 5), all metered between the MFMAs (the source order IS the issue order, pinned with
 //     sched_barrier like the F(2x2) kernels); V is double buffered, one barrier per k-tile.
@@ -44,7 +44,10 @@ namespace {
 //   narrow WT = 2, WC = 2, KT = 16:  32 tiles x  64 channels  (Cout %  64 == 0, Cin % 16 == 0: the 64-channel layers; two
 //          waves share every weight fragment through the L1, V keeps its 72 KiB per stage with half the channels)
 constexpr int WINO43_LDS_BYTES = 2 * 36 * 16 * 32 * 4;      // V: 2 stages x 36 xi x (16 WT tiles) x KT channels = 144 KiB for both shapes
-constexpr int RING = 4;                       // weight-fragment ring slots (groups in flight = RING - 1)
+#ifndef GLASS_W43_RING
+#define GLASS_W43_RING 6       // 4 (three groups = ~770 cycles ahead) until round 6: under a full grid the L2 answers later (k-tile 22.1 K cycles at 32 workgroups, 23.1 K at 2048); 6 is +0.6 - 1.3 % end to end on two boxes, 9 spills and loses (profiles/r06_ab_w43_ring.txt)
+#endif
+constexpr int RING = GLASS_W43_RING;          // weight-fragment ring slots (groups in flight = RING - 1)
 #ifndef GLASS_W43_VACC_XI
 #define GLASS_W43_VACC_XI 32
 #endif
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino43_f32(WinoParams p) {
         constexpr int m = decltype(m_)::value;
         constexpr int s = m >> 1, cb = m & 1;
         // side work issued BEFORE MFMA (u, m)
-        if constexpr (m == 0 || m == 2) {                 // weight fragments of the group three ahead
+        if constexpr (m == 0 || m == 2) {                 // weight fragments of the group RING - 1 ahead
           constexpr int u3 = u + RING - 1;
           if constexpr (u3 < NG) load_a1(kt, u3, m >> 1); else load_a1(ktn, u3 - NG, m >> 1);
           __builtin_amdgcn_sched_barrier(0);
