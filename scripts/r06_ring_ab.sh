@@ -1,7 +1,9 @@
 #!/bin/bash
-# F(4x4) weight ring depth: 4 slots (3 groups = 768 cycles ahead, the product) vs 6 (5 groups ahead)
+# F(4x4) schedule variants (variant libraries of one source tree; $VARIANTS): phase stamps at a full grid, per-layer times, alternating end-to-end runs
 cd "$GRAFT_REPO_ROOT"; R=$GRAFT_REPO_ROOT/glass-text-spotting_amd
-for v in ring6 ring9; do echo "== $v"; GLASS_HIP_LIB=$R/libglass_hip_$v.so W43_LAYERS=0,1,2,3 python scripts/bench_w43.py 2>&1 | grep ABL; done
-for i in 1 2 3; do for v in ring4 ring6 ring9; do
+V=${VARIANTS:-"base r8 v0 r8v0"}
+for v in $V; do echo "== $v"; GLASS_HIP_LIB=$R/libglass_hip_$v.so python scripts/exp_w43_epilogue.py 2>&1 | grep -A1 "2048 workgroups" | grep dbg | sed 's/ | block life.*//'
+  GLASS_HIP_LIB=$R/libglass_hip_$v.so W43_LAYERS=0,1,2,3 python scripts/bench_w43.py 2>&1 | grep ABL; done
+for i in 1 2 3; do for v in $V; do
   echo -n "[$v] "; GLASS_HIP_LIB=$R/libglass_hip_$v.so timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 100 2>/dev/null | python scripts/ab_line.py
 done; done
